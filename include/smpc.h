@@ -1,0 +1,316 @@
+/*
+ * smpc.h — C-ABI of the MI355X-native sampling-MPC hot path.
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (soham2560/MPCHoloNavigation, package nav2_sortham_controller): the body of
+ * sortham::Optimizer::optimize() — noise add, holonomic rollout, critic
+ * scoring, softmax-weighted control update — i.e. everything between
+ * Optimizer::prepare() and utils::savitskyGolayFilter() in
+ * Optimizer::evalControl() (reference src/optimizer.cpp:134-164).
+ *
+ * Plain C, plain pointers and sizes; no C++/torch/ROS types cross it.
+ * Every entry point cites the reference interface it replaces as
+ * [ref file:line], paths relative to nav2_sortham_controller/.
+ *
+ * Conventions
+ *   - every function returning int returns SMPC_OK (0) or a negative
+ *     SMPC_ERR_* code; smpc_last_error(ctx) gives the text.  No exception
+ *     crosses the ABI.  "All trajectories collide" is NOT an error: it is
+ *     smpc_tick_out.fail_flag = 1 and the host runs Optimizer::fallback()
+ *     [ref src/optimizer.cpp:166-183].
+ *   - the caller owns every pointer it passes; the library copies what it
+ *     needs before returning (device pointers in the *_device entry points
+ *     are the exception and are documented there).
+ *   - a ctx is used by one thread at a time [ref src/controller.cpp:94-103
+ *     holds the parameter and costmap mutexes around the whole tick];
+ *     distinct ctx are independent (the reference's function-static retry
+ *     counter, src/optimizer.cpp:168, is per-host-object here).
+ *   - tensors are row-major [batch, time] float32 exactly like the
+ *     reference's xt::xtensor<float,2> members [ref models/state.hpp:30-57].
+ */
+#ifndef SMPC_H_
+#define SMPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMPC_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+#define SMPC_OK 0
+#define SMPC_ERR_INVALID -1     /* bad argument / inconsistent sizes          */
+#define SMPC_ERR_UNSUPPORTED -2 /* feature outside the hot-path scope         */
+#define SMPC_ERR_DEVICE -3      /* HIP runtime error (text in last_error)     */
+#define SMPC_ERR_STATE -4       /* call order (no costmap / no noise yet)     */
+#define SMPC_ERR_NOMEM -5
+
+/* ---- costmap cost constants [nav2_costmap_2d cost_values.hpp; used at
+ *      ref src/critics/obstacles_critic.cpp:185-201, tools/utils.hpp:374-386] */
+#define SMPC_COST_NO_INFORMATION 255
+#define SMPC_COST_LETHAL 254
+#define SMPC_COST_INSCRIBED 253
+#define SMPC_COST_FREE 0
+
+/* ---- motion models [ref include/.../motion_models.hpp:85-171].
+ *      Only the holonomic Omni model is on the hot path (north star).      */
+#define SMPC_MODEL_OMNI 0
+
+/* ---- smpc_config.flags ------------------------------------------------- */
+#define SMPC_FLAG_STORE_TRAJECTORIES 0x1u /* materialise x,y,yaw [B,T] each
+                                             pass so smpc_get_trajectories()
+                                             works [ref optimizer.cpp:455-458] */
+#define SMPC_FLAG_NO_SPECULATION 0x2u     /* always run the furthest-point
+                                             pre-pass (exact two-pass mode)  */
+
+/*
+ * Optimizer settings.  Mirrors sortham::models::OptimizerSettings,
+ * ControlConstraints and SamplingStd
+ * [ref models/optimizer_settings.hpp:28-41, models/constraints.hpp:25-42];
+ * defaults are the ones Optimizer::getParams() declares
+ * [ref src/optimizer.cpp:69-82]; see smpc_config_default().
+ */
+typedef struct smpc_config {
+  uint32_t batch_size;      /* B, this ctx's rollouts (a shard when sharded) */
+  uint32_t time_steps;      /* T                                             */
+  uint32_t iteration_count; /* optimize() iterations per tick                */
+  uint32_t motion_model;    /* SMPC_MODEL_OMNI                               */
+  float model_dt;
+  float temperature;
+  float gamma;
+  float vx_max, vx_min, vy_max, wz_max; /* base constraints                   */
+  float vx_std, vy_std, wz_std;         /* sampling std                       */
+  int32_t device;                       /* HIP device ordinal, -1 = current   */
+  uint32_t flags;                       /* SMPC_FLAG_*                        */
+  /* batch sharding: this ctx holds rows
+   * [shard_offset, shard_offset+batch_size) of a global batch of
+   * global_batch_size rollouts.  0/0 means "not sharded". */
+  uint64_t shard_offset;
+  uint64_t global_batch_size;
+} smpc_config;
+
+/*
+ * Critic parameters: the five critics the north star names, each with the
+ * parameter names and defaults of its initialize()
+ * [ref src/critics/obstacles_critic.cpp:21-51, path_align_critic.cpp:26-44,
+ *  path_follow_critic.cpp:23-33, goal_angle_critic.cpp:20-34,
+ *  prefer_forward_critic.cpp:20-31].  `enabled` mirrors CriticFunction's
+ * enabled_ [ref critic_function.hpp:65-106] AND membership in the YAML
+ * `critics` list [ref src/critic_manager.cpp:36-60].
+ */
+typedef struct smpc_obstacles_params {
+  int32_t enabled;
+  int32_t consider_footprint; /* must be 0: point ("circular") mode only      */
+  uint32_t cost_power;
+  float repulsion_weight;
+  float critical_weight;
+  float collision_cost;
+  float collision_margin_distance;
+  float near_goal_distance;
+} smpc_obstacles_params;
+
+typedef struct smpc_path_align_params {
+  int32_t enabled;
+  int32_t use_path_orientations;
+  uint32_t cost_power;
+  float cost_weight;
+  float max_path_occupancy_ratio;
+  uint32_t offset_from_furthest;
+  uint32_t trajectory_point_step;
+  float threshold_to_consider;
+} smpc_path_align_params;
+
+typedef struct smpc_path_follow_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  float threshold_to_consider;
+  uint32_t offset_from_furthest;
+} smpc_path_follow_params;
+
+typedef struct smpc_goal_angle_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  float threshold_to_consider;
+} smpc_goal_angle_params;
+
+typedef struct smpc_prefer_forward_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  float threshold_to_consider;
+} smpc_prefer_forward_params;
+
+typedef struct smpc_critic_params {
+  smpc_obstacles_params obstacles;
+  smpc_path_align_params path_align;
+  smpc_path_follow_params path_follow;
+  smpc_goal_angle_params goal_angle;
+  smpc_prefer_forward_params prefer_forward;
+} smpc_critic_params;
+
+/*
+ * Per-tick inputs: what Optimizer::prepare() copies into the optimizer
+ * [ref src/optimizer.cpp:185-204] plus the sticky fail flag the critic
+ * manager consults [ref src/critic_manager.cpp:67-76].
+ */
+typedef struct smpc_tick_in {
+  double pose_x, pose_y; /* state.pose.pose.position (double in the msg)       */
+  float pose_yaw;        /* (float)tf2::getYaw(orientation) [optimizer.cpp:317] */
+  double speed_vx, speed_vy, speed_wz; /* state.speed (Twist, double)          */
+  const float* path_x;   /* utils::toTensor(plan) [ref tools/utils.hpp:180-192] */
+  const float* path_y;
+  const float* path_yaw;
+  uint32_t path_len;     /* P                                                  */
+  double goal_x, goal_y; /* goal.position                                      */
+  /* Optional P-1 entries of CriticData::path_pts_valid
+   * [ref tools/utils.hpp:361-395]; NULL = derive from the ctx's costmap.     */
+  const uint8_t* path_pts_valid;
+  /* 1 = CriticData::fail_flag is already set (retry after fallback():
+   * CriticManager scores nothing) [ref critic_manager.cpp:70-73].            */
+  int32_t fail_flag_in;
+} smpc_tick_in;
+
+typedef struct smpc_tick_out {
+  int32_t fail_flag;        /* all trajectories collide [obstacles_critic.cpp:177] */
+  int32_t furthest_valid;   /* furthest_reached_path_point was evaluated           */
+  uint32_t furthest_reached_path_point; /* [ref tools/utils.hpp:292-319]           */
+  uint32_t non_colliding;   /* rollouts that did not collide (last iteration)      */
+  float min_cost;           /* xt::amin(costs_) of the last iteration              */
+  float sum_w;              /* sum of exp weights of the last iteration            */
+  uint32_t passes;          /* scoring passes over the noise (speculation misses
+                               show up as passes > iteration_count)               */
+  float device_ms;          /* GPU time of this call's kernels (HIP events)        */
+} smpc_tick_out;
+
+typedef struct smpc_ctx smpc_ctx;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Fill *cfg with Optimizer::getParams() defaults [ref src/optimizer.cpp:69-82]
+ * (motion model Omni, device -1, flags 0). */
+void smpc_config_default(smpc_config* cfg);
+
+/* Fill *p with every critic's initialize() defaults, all five enabled. */
+void smpc_critic_params_default(smpc_critic_params* p);
+
+/* Replaces Optimizer::initialize()'s allocation half + reset()
+ * [ref src/optimizer.cpp:35-55,116-132].  Control-sequence state is NOT kept
+ * in the ctx: u travels through smpc_optimize(u_inout), as control_sequence_
+ * stays a host member in the reference. */
+int smpc_create(const smpc_config* cfg, smpc_ctx** out);
+void smpc_destroy(smpc_ctx* ctx);
+
+/* Text of the last error on this ctx (never NULL).  ctx may be NULL for the
+ * last smpc_create() failure of the calling thread. */
+const char* smpc_last_error(const smpc_ctx* ctx);
+
+/* ABI version and build string. */
+int smpc_abi_version(void);
+const char* smpc_build_info(void);
+
+/* ---- configuration ------------------------------------------------------ */
+
+/* NoiseGenerator::reset() half of Optimizer::reset()
+ * [ref src/noise_generator.cpp:76-95]: in device-RNG mode re-draws the noise
+ * (next draw epoch); in supplied-noise mode keeps the arrays given to
+ * smpc_set_noise().  Also drops cached per-tick state. */
+int smpc_reset(smpc_ctx* ctx);
+
+/* Current (speed-limited) constraints used by
+ * applyControlSequenceConstraints() [ref src/optimizer.cpp:237-249,428-453]. */
+int smpc_set_constraints(smpc_ctx* ctx, float vx_max, float vx_min, float vy_max,
+                         float wz_max);
+
+int smpc_set_critics(smpc_ctx* ctx, const smpc_critic_params* p);
+
+/* Replaces the Costmap2D* the critics hold
+ * [ref src/critics/obstacles_critic.cpp:32,203-224, tools/utils.hpp:361-395].
+ * cells: uint8[height*width], index my*width+mx (Costmap2D::getCost).
+ * inscribed_radius: LayeredCostmap::getInscribedRadius().
+ * cost_scaling_factor / inflation_radius: ObstaclesCritic's parameters of the
+ * same name, read only when the costmap has an InflationLayer
+ * [ref obstacles_critic.cpp:70-80]; pass 0,0 when it has none. */
+int smpc_set_costmap(smpc_ctx* ctx, const uint8_t* cells, uint32_t width,
+                     uint32_t height, double origin_x, double origin_y,
+                     double resolution, int track_unknown, float inscribed_radius,
+                     float cost_scaling_factor, float inflation_radius);
+
+/* Supplied-noise (parity) mode: the three [B,T] row-major noise tensors
+ * NoiseGenerator holds [ref tools/noise_generator.hpp:97-99], already scaled
+ * by the sampling std.  Host pointers; copied. */
+int smpc_set_noise(smpc_ctx* ctx, const float* noise_vx, const float* noise_vy,
+                   const float* noise_wz);
+
+/* Device-RNG mode: Philox4x32-10 + Box–Muller, draw order vx, wz, vy
+ * [ref src/noise_generator.cpp:107-122].  Draw epoch 0 is drawn here; each
+ * smpc_reset() draws the next epoch (the reference's first tick also runs on
+ * its second draw, optimizer.cpp:52-54). */
+int smpc_seed(smpc_ctx* ctx, uint64_t seed);
+
+/* Copy the ctx's noise tensors back (tests / RNG parity). Any pointer may be NULL. */
+int smpc_get_noise(smpc_ctx* ctx, float* noise_vx, float* noise_vy, float* noise_wz);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/* Replaces the body of Optimizer::optimize() [ref src/optimizer.cpp:157-164]:
+ * iteration_count x { generateNoisedTrajectories (:227-233),
+ * CriticManager::evalTrajectoriesScores (critic_manager.cpp:67-76),
+ * updateControlSequence (:362-394) }, costs_ zeroed once per call as
+ * prepare() does (:197).
+ * u_inout: control_sequence_ as 3*T floats {vx[T], vy[T], wz[T]}, host memory. */
+int smpc_optimize(smpc_ctx* ctx, const smpc_tick_in* in, float* u_inout,
+                  smpc_tick_out* out);
+
+/* Optimizer::getGeneratedTrajectories() [ref src/optimizer.cpp:455-458]:
+ * x, y, yaws [B,T] of the last scoring pass.  Needs
+ * SMPC_FLAG_STORE_TRAJECTORIES.  Any pointer may be NULL. */
+int smpc_get_trajectories(smpc_ctx* ctx, float* x, float* y, float* yaws);
+
+/* costs_ [B] after the last iteration (incl. the gamma terms of
+ * updateControlSequence) [ref include/.../optimizer.hpp:255]. */
+int smpc_get_costs(smpc_ctx* ctx, float* costs);
+
+/* ---- batch-sharded path; one ctx per GPU ------------------
+ * A tick on G shards is
+ *   begin -> [furthest -> MAX over ranks] -> score -> all-gather -> combine
+ * where the bracketed exchange is skipped when the caller speculates on the
+ * furthest point (score() reports the true local value in its tuple and the
+ * caller re-scores on a miss).  The two exchanges are done by the caller
+ * (RCCL through torch.distributed in bench.py); the library never blocks on a
+ * peer.  All device pointers must be on this ctx's device and all work is
+ * enqueued on the stream given to smpc_set_stream(). */
+
+/* hipStream_t to enqueue on (NULL = the ctx's own stream). */
+int smpc_set_stream(smpc_ctx* ctx, void* hip_stream);
+
+#define SMPC_TUPLE_HEADER 4 /* floats before U: min, sum_w, furthest, non_colliding */
+/* Length in floats of one shard tuple: SMPC_TUPLE_HEADER + 3*T. */
+uint32_t smpc_tuple_len(const smpc_ctx* ctx);
+
+/* Upload the tick's inputs and control sequence (host pointers). */
+int smpc_shard_begin(smpc_ctx* ctx, const smpc_tick_in* in, const float* u_in);
+/* Local max over this shard of the nearest-path-point index of each rollout's
+ * endpoint [ref tools/utils.hpp:292-319], written as one float to d_furthest. */
+int smpc_shard_furthest(smpc_ctx* ctx, float* d_furthest);
+/* Score this shard with the batch-wide furthest point read from d_furthest
+ * (device, one float) or, if d_furthest is NULL, furthest_hint; writes the
+ * shard tuple {min cost, sum w, true local furthest, non-colliding count,
+ * sum w*cvx[T], sum w*cvy[T], sum w*cwz[T]} to d_tuple (device). */
+int smpc_shard_score(smpc_ctx* ctx, const float* d_furthest, uint32_t furthest_hint,
+                     float* d_tuple);
+/* Combine n_tuples shard tuples (device, contiguous) into the new control
+ * sequence: rescale by exp(-(min_g - min)/temperature), divide, clip
+ * [ref src/optimizer.cpp:382-393]; copies u (3*T) to host and fills *out.
+ * Synchronises the stream. */
+int smpc_shard_combine(smpc_ctx* ctx, const float* d_tuples, uint32_t n_tuples,
+                       float* u_out, smpc_tick_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMPC_H_ */

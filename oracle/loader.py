@@ -1,0 +1,203 @@
+"""ctypes loader for the CPU oracle — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline
+leg.  Nothing under mpcholonavigation_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mpcholonavigation_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ctx = C.c_void_p
+_f32p = C.c_void_p
+
+_PROTOTYPES = {
+    "smpc_oracle_create": (C.c_int, [C.POINTER(A.SmpcConfig), C.POINTER(_ctx)]),
+    "smpc_oracle_destroy": (None, [_ctx]),
+    "smpc_oracle_last_error": (C.c_char_p, [_ctx]),
+    "smpc_oracle_build_info": (C.c_char_p, []),
+    "smpc_oracle_reset": (C.c_int, [_ctx]),
+    "smpc_oracle_set_constraints": (C.c_int, [_ctx, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "smpc_oracle_set_critics": (C.c_int, [_ctx, C.POINTER(A.SmpcCriticParams)]),
+    "smpc_oracle_set_costmap": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
+                                          C.c_double, C.c_double, C.c_int, C.c_float, C.c_float,
+                                          C.c_float]),
+    "smpc_oracle_set_noise": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    "smpc_oracle_seed": (C.c_int, [_ctx, C.c_uint64]),
+    "smpc_oracle_get_noise": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    "smpc_oracle_set_accumulate_double": (C.c_int, [_ctx, C.c_int]),
+    "smpc_oracle_optimize": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p,
+                                       C.POINTER(A.SmpcTickOut)]),
+    "smpc_oracle_get_trajectories": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    "smpc_oracle_get_costs": (C.c_int, [_ctx, _f32p]),
+    "smpc_oracle_shard_furthest": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p, _f32p]),
+    "smpc_oracle_shard_score": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p, C.c_uint32,
+                                          _f32p]),
+    "smpc_oracle_shard_combine": (C.c_int, [_ctx, _f32p, C.c_uint32, _f32p,
+                                            C.POINTER(A.SmpcTickOut)]),
+    "smpc_oracle_set_state_velocities": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    "smpc_oracle_set_trajectories": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    "smpc_oracle_update_state_velocities": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p,
+                                                      _f32p, _f32p]),
+    "smpc_oracle_get_state_velocities": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
+    "smpc_oracle_integrate": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn)]),
+    "smpc_oracle_score_critic": (C.c_int, [_ctx, C.c_int, C.POINTER(A.SmpcTickIn), C.c_int64,
+                                           _f32p, C.POINTER(C.c_int32)]),
+    "smpc_oracle_within_position_goal_tolerance": (C.c_int, [C.c_float, C.c_double, C.c_double,
+                                                             C.c_double, C.c_double]),
+    "smpc_oracle_normalize_angles": (None, [_f32p, C.c_void_p, C.c_uint32]),
+    "smpc_oracle_shortest_angular_distance": (None, [_f32p, C.c_float, C.c_void_p, C.c_uint32]),
+    "smpc_oracle_find_path_furthest_reached_point": (C.c_uint32, [_f32p, _f32p, C.c_uint32,
+                                                                  C.c_uint32, _f32p, _f32p,
+                                                                  C.c_uint32]),
+    "smpc_oracle_find_path_trajectory_initial_point": (C.c_uint32, [C.c_float, C.c_float, _f32p,
+                                                                    _f32p, C.c_uint32]),
+    "smpc_oracle_find_path_costs": (C.c_int, [_ctx, _f32p, _f32p, C.c_uint32, C.c_void_p]),
+    "smpc_oracle_find_closest_path_pt": (C.c_uint32, [_f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "smpc_oracle_apply_constraints": (None, [_f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                             C.c_float]),
+    "smpc_oracle_shift_control_sequence": (None, [_f32p, C.c_uint32]),
+    "smpc_oracle_savitsky_golay": (None, [_f32p, C.c_uint32, _f32p, C.c_int]),
+    "smpc_oracle_speed_limit": (None, [_f32p, C.c_double, C.c_int, _f32p]),
+    "smpc_oracle_set_offset": (C.c_int, [C.c_double, C.c_float]),
+    "smpc_oracle_philox4x32_10": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smpc_config_default": (None, [C.POINTER(A.SmpcConfig)]),
+    "smpc_critic_params_default": (None, [C.POINTER(A.SmpcCriticParams)]),
+}
+
+_libs = {}
+
+
+def build():
+    """Compile both oracle builds (strict checker + reference-flags baseline)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def load(fast=False):
+    """Load liboracle.so (strict) or liboracle_fast.so (reference flags)."""
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name not in _libs:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        A.bind(lib, _PROTOTYPES)
+        _libs[name] = lib
+    return _libs[name]
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Thin object wrapper over the smpc_oracle_* C-ABI."""
+
+    def __init__(self, cfg, fast=False):
+        self.lib = load(fast)
+        self.cfg = cfg
+        self.B, self.T = cfg.batch_size, cfg.time_steps
+        h = _ctx()
+        rc = self.lib.smpc_oracle_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"smpc_oracle_create failed: {rc}")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.smpc_oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(
+                f"oracle error {rc}: {self.lib.smpc_oracle_last_error(self.h).decode()}")
+
+    def reset(self):
+        self._ck(self.lib.smpc_oracle_reset(self.h))
+
+    def set_constraints(self, vx_max, vx_min, vy_max, wz_max):
+        self._ck(self.lib.smpc_oracle_set_constraints(self.h, vx_max, vx_min, vy_max, wz_max))
+
+    def set_critics(self, p):
+        self._ck(self.lib.smpc_oracle_set_critics(self.h, C.byref(p)))
+
+    def set_costmap(self, cells, origin_x, origin_y, resolution, track_unknown=False,
+                    inscribed_radius=0.1, cost_scaling_factor=10.0, inflation_radius=0.55):
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        h, w = cells.shape
+        self._ck(self.lib.smpc_oracle_set_costmap(
+            self.h, ptr(cells), w, h, origin_x, origin_y, resolution, int(track_unknown),
+            inscribed_radius, cost_scaling_factor, inflation_radius))
+
+    def set_noise(self, nvx, nvy, nwz):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (nvx, nvy, nwz)]
+        for x in a:
+            assert x.shape == (self.B, self.T)
+        self._ck(self.lib.smpc_oracle_set_noise(self.h, ptr(a[0]), ptr(a[1]), ptr(a[2])))
+
+    def seed(self, seed):
+        self._ck(self.lib.smpc_oracle_seed(self.h, seed))
+
+    def get_noise(self):
+        out = [np.empty((self.B, self.T), np.float32) for _ in range(3)]
+        self._ck(self.lib.smpc_oracle_get_noise(self.h, ptr(out[0]), ptr(out[1]), ptr(out[2])))
+        return out
+
+    def set_accumulate_double(self, on):
+        self._ck(self.lib.smpc_oracle_set_accumulate_double(self.h, int(on)))
+
+    def optimize(self, tick, u):
+        """u: float32 [3, T] (vx, vy, wz); returns (u_new, SmpcTickOut)."""
+        u = np.ascontiguousarray(u, dtype=np.float32).copy()
+        out = A.SmpcTickOut()
+        self._ck(self.lib.smpc_oracle_optimize(self.h, C.byref(tick.c), ptr(u), C.byref(out)))
+        return u, out
+
+    def get_trajectories(self):
+        out = [np.empty((self.B, self.T), np.float32) for _ in range(3)]
+        self._ck(self.lib.smpc_oracle_get_trajectories(self.h, ptr(out[0]), ptr(out[1]),
+                                                       ptr(out[2])))
+        return out
+
+    def get_costs(self):
+        c = np.empty(self.B, np.float32)
+        self._ck(self.lib.smpc_oracle_get_costs(self.h, ptr(c)))
+        return c
+
+    # shard phases
+    def shard_furthest(self, tick, u):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        f = np.zeros(1, np.float32)
+        self._ck(self.lib.smpc_oracle_shard_furthest(self.h, C.byref(tick.c), ptr(u), ptr(f)))
+        return float(f[0])
+
+    def shard_score(self, tick, u, furthest):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        t = np.zeros(A.SMPC_TUPLE_HEADER + 3 * self.T, np.float32)
+        self._ck(self.lib.smpc_oracle_shard_score(self.h, C.byref(tick.c), ptr(u), int(furthest),
+                                                  ptr(t)))
+        return t
+
+    def shard_combine(self, tuples):
+        tuples = np.ascontiguousarray(tuples, dtype=np.float32)
+        n = tuples.shape[0]
+        u = np.zeros((3, self.T), np.float32)
+        out = A.SmpcTickOut()
+        self._ck(self.lib.smpc_oracle_shard_combine(self.h, ptr(tuples), n, ptr(u),
+                                                    C.byref(out)))
+        return u, out

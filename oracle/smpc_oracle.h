@@ -1,0 +1,125 @@
+/*
+ * smpc_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * C-ABI of the CPU restatement ("oracle") of the reference's sampling-MPC hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; nothing under mpcholonavigation_amd/ does.
+ *
+ * It reuses the plain-C structs of include/smpc.h so that a parity test
+ * builds ONE set of inputs and hands it to both libraries.
+ */
+#ifndef SMPC_ORACLE_H_
+#define SMPC_ORACLE_H_
+
+#include "../include/smpc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smpc_oracle smpc_oracle;
+
+/* critic ids for smpc_oracle_score_critic() */
+#define SMPC_ORACLE_CRITIC_OBSTACLES 0
+#define SMPC_ORACLE_CRITIC_PATH_ALIGN 1
+#define SMPC_ORACLE_CRITIC_PATH_FOLLOW 2
+#define SMPC_ORACLE_CRITIC_GOAL_ANGLE 3
+#define SMPC_ORACLE_CRITIC_PREFER_FORWARD 4
+
+int smpc_oracle_create(const smpc_config* cfg, smpc_oracle** out);
+void smpc_oracle_destroy(smpc_oracle* o);
+const char* smpc_oracle_last_error(const smpc_oracle* o);
+const char* smpc_oracle_build_info(void);
+
+int smpc_oracle_reset(smpc_oracle* o);
+int smpc_oracle_set_constraints(smpc_oracle* o, float vx_max, float vx_min, float vy_max,
+                                float wz_max);
+int smpc_oracle_set_critics(smpc_oracle* o, const smpc_critic_params* p);
+int smpc_oracle_set_costmap(smpc_oracle* o, const uint8_t* cells, uint32_t width,
+                            uint32_t height, double origin_x, double origin_y,
+                            double resolution, int track_unknown, float inscribed_radius,
+                            float cost_scaling_factor, float inflation_radius);
+int smpc_oracle_set_noise(smpc_oracle* o, const float* nvx, const float* nvy,
+                          const float* nwz);
+int smpc_oracle_seed(smpc_oracle* o, uint64_t seed);
+int smpc_oracle_get_noise(smpc_oracle* o, float* nvx, float* nvy, float* nwz);
+
+/* 1: accumulate the batch-wide sums of updateControlSequence in double
+ * (diagnostic: separates kernel error from the reference's own float
+ * accumulation error at large B).  Default 0 = float like the reference. */
+int smpc_oracle_set_accumulate_double(smpc_oracle* o, int on);
+
+int smpc_oracle_optimize(smpc_oracle* o, const smpc_tick_in* in, float* u_inout,
+                         smpc_tick_out* out);
+int smpc_oracle_get_trajectories(smpc_oracle* o, float* x, float* y, float* yaws);
+int smpc_oracle_get_costs(smpc_oracle* o, float* costs);
+
+/* shard phases (same meaning as smpc_shard_*; host memory everywhere) */
+int smpc_oracle_shard_furthest(smpc_oracle* o, const smpc_tick_in* in, const float* u_in,
+                               float* furthest);
+int smpc_oracle_shard_score(smpc_oracle* o, const smpc_tick_in* in, const float* u_in,
+                            uint32_t furthest, float* tuple);
+int smpc_oracle_shard_combine(smpc_oracle* o, const float* tuples, uint32_t n_tuples,
+                              float* u_out, smpc_tick_out* out);
+
+/* ---- piece-wise entry points, used to re-encode the reference's own
+ *      known-answer tests against the restatement ------------------------- */
+
+/* Overwrite state velocities / trajectories [B,T] (any pointer may be NULL). */
+int smpc_oracle_set_state_velocities(smpc_oracle* o, const float* vx, const float* vy,
+                                     const float* wz);
+int smpc_oracle_set_trajectories(smpc_oracle* o, const float* x, const float* y,
+                                 const float* yaws);
+/* Optimizer::updateStateVelocities on given control tensors cvx,cvy,cwz [B,T];
+ * results readable through smpc_oracle_get_state_velocities. */
+int smpc_oracle_update_state_velocities(smpc_oracle* o, const smpc_tick_in* in,
+                                        const float* cvx, const float* cvy,
+                                        const float* cwz);
+int smpc_oracle_get_state_velocities(smpc_oracle* o, float* vx, float* vy, float* wz);
+/* Optimizer::integrateStateVelocities(Trajectories&, State&) on the stored state. */
+int smpc_oracle_integrate(smpc_oracle* o, const smpc_tick_in* in);
+/* One critic's score() on the stored state/trajectories; costs_inout [B] is
+ * added to.  furthest_preset >= 0 presets CriticData::furthest_reached_path_point. */
+int smpc_oracle_score_critic(smpc_oracle* o, int critic_id, const smpc_tick_in* in,
+                             int64_t furthest_preset, float* costs_inout,
+                             int32_t* fail_flag_out);
+
+/* utils.hpp helpers */
+int smpc_oracle_within_position_goal_tolerance(float tol, double px, double py, double gx,
+                                               double gy);
+void smpc_oracle_normalize_angles(const float* in, double* out, uint32_t n);
+/* shortest_angular_distance(from[], to) as GoalAngleCritic uses it */
+void smpc_oracle_shortest_angular_distance(const float* from, float to, double* out,
+                                           uint32_t n);
+uint32_t smpc_oracle_find_path_furthest_reached_point(const float* traj_x,
+                                                      const float* traj_y, uint32_t B,
+                                                      uint32_t T, const float* path_x,
+                                                      const float* path_y, uint32_t P);
+uint32_t smpc_oracle_find_path_trajectory_initial_point(float x00, float y00,
+                                                        const float* path_x,
+                                                        const float* path_y, uint32_t P);
+/* findPathCosts on the oracle's costmap: valid_out has P-1 entries. */
+int smpc_oracle_find_path_costs(smpc_oracle* o, const float* path_x, const float* path_y,
+                                uint32_t P, uint8_t* valid_out);
+uint32_t smpc_oracle_find_closest_path_pt(const float* vec, uint32_t n, float dist,
+                                          uint32_t init);
+
+/* host-side control-sequence helpers (u = {vx[T], vy[T], wz[T]}) */
+void smpc_oracle_apply_constraints(float* u, uint32_t T, float vx_max, float vx_min,
+                                   float vy_max, float wz_max);
+void smpc_oracle_shift_control_sequence(float* u, uint32_t T);
+/* history: 4 x {vx, vy, wz}, oldest first [ref optimizer.hpp control_history_] */
+void smpc_oracle_savitsky_golay(float* u, uint32_t T, float* history, int shift);
+/* constraints_out = {vx_max, vx_min, vy, wz} */
+void smpc_oracle_speed_limit(const float* base, double speed_limit, int percentage,
+                             float* constraints_out);
+/* returns 0 = warn (period < dt), 1 = shift on, -1 = throws */
+int smpc_oracle_set_offset(double controller_frequency, float model_dt);
+
+/* Philox4x32-10 block (counter c[4], key k[2]) -> out[4]; RNG pinning */
+void smpc_oracle_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

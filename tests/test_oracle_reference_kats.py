@@ -1,0 +1,352 @@
+"""Pins the CPU oracle against the reference's OWN known-answer tests.
+
+The reference (soham2560/MPCHoloNavigation, nav2_sortham_controller) cannot be
+built here (ROS 2 Humble / nav2 / xtensor absent), so every value assertion its
+gtest files make on the hot path is re-encoded against the restatement, with
+the same inputs and tolerances.  Each test names the reference test it encodes
+(paths relative to nav2_sortham_controller/).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from mpcholonavigation_amd import _abi as A
+from mpcholonavigation_amd.tick import Tick, default_config, default_critics
+from oracle import loader
+from oracle.loader import Oracle, ptr
+
+CRITIC = dict(obstacles=0, path_align=1, path_follow=2, goal_angle=3, prefer_forward=4)
+
+
+def _tick(pose_x=0.0, pose_y=0.0, yaw=0.0, speed=(0.0, 0.0, 0.0), path=None, goal=(0.0, 0.0)):
+    if path is None:
+        path = (np.zeros(1, np.float32),) * 3
+    return Tick(pose_x, pose_y, yaw, speed, path[0], path[1], path[2], goal[0], goal[1])
+
+
+def _blank_costmap(o, size=50, res=0.1):
+    # "Costmap defaults to size 5x5 @ 10cm resolution" (test/critics_tests.cpp:546)
+    cells = np.zeros((size, size), np.uint8)
+    o.set_costmap(cells, 0.0, 0.0, res, inscribed_radius=0.0, cost_scaling_factor=0.0,
+                  inflation_radius=0.0)
+    return cells
+
+
+def _score(o, name, tick, costs, furthest=-1):
+    fail = C.c_int32(0)
+    rc = o.lib.smpc_oracle_score_critic(o.h, CRITIC[name], C.byref(tick.c), furthest, ptr(costs),
+                                        C.byref(fail))
+    return rc, fail.value
+
+
+# --------------------------------------------------------------------------
+# test/optimizer_unit_tests.cpp
+# --------------------------------------------------------------------------
+
+def test_integrate_state_velocities_kat():
+    """optimizer_unit_tests.cpp:577-639 integrateStateVelocitiesTests."""
+    B, T = 1000, 50
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1))
+    tick = _tick()
+    vx = np.full((B, T), 0.1, np.float32)
+    vx[:, 0] = 0
+    vy = np.zeros((B, T), np.float32)
+    wz = np.zeros((B, T), np.float32)
+    o.lib.smpc_oracle_set_state_velocities(o.h, ptr(vx), ptr(vy), ptr(wz))
+    o.lib.smpc_oracle_integrate(o.h, C.byref(tick.c))
+    x, y, yaws = o.get_trajectories()
+    assert np.array_equal(y, np.zeros((B, T), np.float32))
+    assert np.array_equal(yaws, np.zeros((B, T), np.float32))
+    for i in range(T):
+        assert abs(x[1, i] - i * 0.1 * 0.1) < 1e-3
+
+    vy = np.full((B, T), 0.2, np.float32)
+    vy[:, 0] = 0
+    o.lib.smpc_oracle_set_state_velocities(o.h, None, ptr(vy), None)
+    o.lib.smpc_oracle_integrate(o.h, C.byref(tick.c))
+    x, y, yaws = o.get_trajectories()
+    assert np.array_equal(yaws, np.zeros((B, T), np.float32))
+    for i in range(T):
+        assert abs(x[1, i] - i * 0.1 * 0.1) < 1e-3
+        assert abs(y[1, i] - i * 0.2 * 0.1) < 1e-3
+
+    vy = np.zeros((B, T), np.float32)
+    wz = np.full((B, T), 0.2, np.float32)
+    wz[:, 0] = 0
+    o.lib.smpc_oracle_set_state_velocities(o.h, None, ptr(vy), ptr(wz))
+    o.lib.smpc_oracle_integrate(o.h, C.byref(tick.c))
+    x, y, yaws = o.get_trajectories()
+    ex = ey = np.float32(0)
+    for i in range(1, T):
+        # the reference accumulates into a float (float x = 0; x += double expr)
+        ex = np.float32(ex + (0.1 * math.cos(0.2 * 0.1 * (i - 1))) * 0.1)
+        ey = np.float32(ey + (0.1 * math.sin(0.2 * 0.1 * (i - 1))) * 0.1)
+        assert abs(x[1, i] - ex) < 1e-6
+        assert abs(y[1, i] - ey) < 1e-6
+
+
+def test_update_state_velocities_kat():
+    """optimizer_unit_tests.cpp:164-204 testupdateStateVels (Omni)."""
+    B, T = 1000, 50
+    o = Oracle(default_config(batch_size=B, time_steps=T))
+    for sign in (1.0, -1.0):
+        tick = _tick(speed=(5.0 * sign, 1.0 * sign, 6.0 * sign))
+        cvx = np.full((B, T), 0.75 * sign, np.float32)
+        cvy = np.full((B, T), 0.5 * sign, np.float32)
+        cwz = np.full((B, T), 0.1 * sign, np.float32)
+        o.lib.smpc_oracle_update_state_velocities(o.h, C.byref(tick.c), ptr(cvx), ptr(cvy),
+                                                  ptr(cwz))
+        vx, vy, wz = (np.empty((B, T), np.float32) for _ in range(3))
+        o.lib.smpc_oracle_get_state_velocities(o.h, ptr(vx), ptr(vy), ptr(wz))
+        assert abs(vx[0, 0] - 5.0 * sign) < 1e-6
+        assert abs(vy[0, 0] - 1.0 * sign) < 1e-6
+        assert abs(wz[0, 0] - 6.0 * sign) < 1e-6
+        assert abs(vx[0, 1] - 0.75 * sign) < 1e-6
+        assert abs(vy[0, 1] - 0.5 * sign) < 1e-6
+        assert abs(wz[0, 1] - 0.1 * sign) < 1e-6
+        # motion_model_tests.cpp:81-126: predict copies controls[:, :-1] to velocities[:, 1:]
+        assert np.array_equal(vx[:, 1:], cvx[:, :-1])
+
+
+def test_apply_control_sequence_constraints_kat(oracle_lib):
+    """optimizer_unit_tests.cpp:458-512 (exact equality)."""
+    T = 50
+    lim = (1.0, -1.0, 0.75, 2.0)
+    for val, exp in ((None, (1.0, 0.75, 2.0)), (5.0, (1.0, 0.75, 2.0)), (-5.0, (-1.0, -0.75, -2.0))):
+        u = np.empty((3, T), np.float32)
+        if val is None:
+            u[0], u[1], u[2] = 1.0, 0.75, 2.0
+        else:
+            u[:] = val
+        oracle_lib.smpc_oracle_apply_constraints(ptr(u), T, *lim)
+        assert np.array_equal(u[0], np.full(T, exp[0], np.float32))
+        assert np.array_equal(u[1], np.full(T, exp[1], np.float32))
+        assert np.array_equal(u[2], np.full(T, exp[2], np.float32))
+
+
+def test_shift_control_sequence_kat(oracle_lib):
+    """optimizer_unit_tests.cpp:378-419."""
+    T = 100
+    u = np.zeros((3, T), np.float32)
+    u[:, 0], u[:, 1], u[:, 2] = 9999, 6, 888
+    oracle_lib.smpc_oracle_shift_control_sequence(ptr(u), T)
+    assert np.all(u[:, 0] == 6) and np.all(u[:, 1] == 888) and np.all(u[:, 2] == 0)
+    # roll + duplicate-last (optimizer.cpp:206-225)
+    v = np.arange(3 * 7, dtype=np.float32).reshape(3, 7)
+    w = v.copy()
+    oracle_lib.smpc_oracle_shift_control_sequence(ptr(w), 7)
+    assert np.array_equal(w[:, :-1], v[:, 1:]) and np.array_equal(w[:, -1], v[:, -1])
+
+
+def test_speed_limit_kat(oracle_lib):
+    """optimizer_unit_tests.cpp:421-456."""
+    base = np.array([0.5, -0.35, 0.5, 1.9], np.float32)
+    out = np.zeros(4, np.float32)
+
+    def lim(speed, pct):
+        oracle_lib.smpc_oracle_speed_limit(ptr(base), speed, int(pct), ptr(out))
+        return out.copy()
+    r = lim(0.0, False)
+    assert r[0] == np.float32(0.5) and r[1] == np.float32(-0.35)
+    r = lim(50.0, True)
+    assert abs(r[0] - 0.25) < 1e-3 and abs(r[1] + 0.175) < 1e-3
+    r = lim(0.0, True)
+    assert r[0] == np.float32(0.5) and r[1] == np.float32(-0.35)
+    r = lim(0.75, False)
+    assert abs(r[0] - 0.75) < 1e-3 and abs(r[1] + 0.5249) < 1e-2
+
+
+def test_set_offset_kat(oracle_lib):
+    """optimizer_unit_tests.cpp:283-305 (model_dt 0.1)."""
+    assert oracle_lib.smpc_oracle_set_offset(1.0, 0.1) == -1     # throws
+    assert oracle_lib.smpc_oracle_set_offset(30.0, 0.1) == 0     # warn, no shift
+    assert oracle_lib.smpc_oracle_set_offset(10.0, 0.1) == 1     # shift on
+
+
+# --------------------------------------------------------------------------
+# test/critics_tests.cpp
+# --------------------------------------------------------------------------
+
+def test_goal_angle_critic_kat():
+    """critics_tests.cpp:118-170: far -> 0; within 0.5 m, yaws 0 vs goal 3.14 -> 9.42."""
+    B, T = 1000, 30
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1))
+    o.set_critics(default_critics())
+    path = [np.zeros(10, np.float32) for _ in range(3)]
+    path[0][9], path[1][9], path[2][9] = 10.0, 0.0, 3.14
+    costs = np.zeros(B, np.float32)
+    for px in (1.0, 9.2):
+        _score(o, "goal_angle", _tick(pose_x=px, path=path, goal=(10.0, 0.0)), costs)
+        assert abs(float(costs.sum())) < 1e-6
+    _score(o, "goal_angle", _tick(pose_x=9.7, path=path, goal=(10.0, 0.0)), costs)
+    assert costs.sum() > 0
+    assert abs(costs[0] - 9.42) < 0.02
+
+
+def test_prefer_forward_critic_kat():
+    """critics_tests.cpp:284-338: vx=+1 -> 0; vx=-1, T=30, dt=0.1 -> 15.0."""
+    B, T = 1000, 30
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1))
+    o.set_critics(default_critics())
+    path = [np.zeros(10, np.float32) for _ in range(3)]
+    path[0][9] = 10.0
+    costs = np.zeros(B, np.float32)
+    _score(o, "prefer_forward", _tick(pose_x=1.0, path=path, goal=(10.0, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    path[0][9] = 0.15
+    vx = np.ones((B, T), np.float32)
+    o.lib.smpc_oracle_set_state_velocities(o.h, ptr(vx), None, None)
+    _score(o, "prefer_forward", _tick(pose_x=1.0, path=path, goal=(0.15, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    vx = -np.ones((B, T), np.float32)
+    o.lib.smpc_oracle_set_state_velocities(o.h, ptr(vx), None, None)
+    _score(o, "prefer_forward", _tick(pose_x=1.0, path=path, goal=(0.15, 0.0)), costs)
+    assert costs.sum() > 0
+    assert abs(costs[0] - 15.0) < 1e-3
+
+
+def test_path_follow_critic_kat():
+    """critics_tests.cpp:403-452: near goal -> 0; path(5)=(0.15,0), trajectories 0 -> 750."""
+    B, T = 1000, 30
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1))
+    o.set_critics(default_critics())
+    _blank_costmap(o)
+    path = [np.zeros(6, np.float32) for _ in range(3)]
+    path[0][5] = 1.8
+    costs = np.zeros(B, np.float32)
+    _score(o, "path_follow", _tick(pose_x=2.0, path=path, goal=(1.8, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    path[0][5] = 0.15
+    _score(o, "path_follow", _tick(pose_x=2.0, path=path, goal=(0.15, 0.0)), costs)
+    assert abs(float(costs.astype(np.float64).sum()) - 750.0) < 1e-2
+
+
+def test_path_align_critic_kat():
+    """critics_tests.cpp:454-562: near -> 0; furthest<20 -> 0; x=0.66 -> 6600; blocked -> 0."""
+    B, T = 1000, 30
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1))
+    o.set_critics(default_critics())
+    cells = _blank_costmap(o)
+    path = [np.zeros(10, np.float32) for _ in range(3)]
+    path[0][9] = 0.85
+    costs = np.zeros(B, np.float32)
+    _score(o, "path_align", _tick(pose_x=1.0, path=path, goal=(0.85, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    # far enough, but the furthest point reached is 0 < offset_from_furthest (20)
+    path[0][9] = 0.15
+    _score(o, "path_align", _tick(pose_x=1.0, path=path, goal=(0.15, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    # critics_tests.cpp:516-520 presets furthest=21 on a 10-point path: the reference
+    # then indexes the path out of range (UB); the oracle refuses instead of guessing.
+    rc, _ = _score(o, "path_align", _tick(pose_x=1.0, path=path, goal=(0.15, 0.0)), costs, 21)
+    assert rc == A.SMPC_ERR_INVALID
+    # valid 22-point path, trajectories at x = 0.66
+    path = [np.zeros(22, np.float32) for _ in range(3)]
+    path[0][:10] = np.float32(0.1) * np.arange(10, dtype=np.float32)
+    path[0][:10] = [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+    path[0][10:] = 0.9
+    tx = np.full((B, T), 0.66, np.float32)
+    o.lib.smpc_oracle_set_trajectories(o.h, ptr(tx), None, None)
+    rc, _ = _score(o, "path_align", _tick(pose_x=0.0, path=path, goal=(0.9, 0.0)), costs, 21)
+    assert rc == 0
+    assert abs(float(costs.astype(np.float64).sum()) - 6600.0) < 1e-2
+    # lethal island: path blocked -> critic stands down
+    cells[11:31, 11:31] = 254
+    o.set_costmap(cells, 0.0, 0.0, 0.1, inscribed_radius=0.0, cost_scaling_factor=0.0,
+                  inflation_radius=0.0)
+    costs[:] = 0
+    path[0][:] = 1.5
+    path[1][:] = 1.5
+    _score(o, "path_align", _tick(pose_x=0.0, path=path, goal=(1.5, 0.0)), costs, 21)
+    assert abs(float(costs.sum())) < 1e-6
+
+
+# --------------------------------------------------------------------------
+# test/utils_test.cpp
+# --------------------------------------------------------------------------
+
+def test_within_position_goal_tolerance_kat(oracle_lib):
+    """utils_test.cpp:127-175 (float-tolerance overload)."""
+    f = oracle_lib.smpc_oracle_within_position_goal_tolerance
+    assert f(0.25, 10.0, 1.0, 0.0, 0.0) == 0
+    assert f(0.25, 10.0, 1.0, 9.8, 0.95) == 1
+    assert f(0.25, 10.0, 1.0, 10.0, 0.76) == 1
+    assert f(0.25, 10.0, 1.0, 9.76, 1.0) == 1
+
+
+def test_angles_kat(oracle_lib):
+    """utils_test.cpp:177-199: normalisation and shortest distance stay in [-pi, pi]."""
+    ang = np.array([(i * i) * (-1 if i % 2 == 0 else 1) for i in range(100)], np.float32)
+    out = np.zeros(100, np.float64)
+    oracle_lib.smpc_oracle_normalize_angles(ptr(ang), ptr(out), 100)
+    assert np.all((out >= -math.pi) & (out <= math.pi))
+    oracle_lib.smpc_oracle_shortest_angular_distance(ptr(ang), 0.0, ptr(out), 100)
+    assert np.all((out >= -math.pi) & (out <= math.pi))
+    # normalised angle is congruent to the input mod 2*pi
+    oracle_lib.smpc_oracle_normalize_angles(ptr(ang), ptr(out), 100)
+    k = (out - ang.astype(np.float64)) / (2 * math.pi)
+    assert np.allclose(k, np.round(k), atol=1e-9)
+
+
+def test_furthest_and_closest_reached_point_kat(oracle_lib):
+    """utils_test.cpp:217-260: both indices are 5."""
+    tx = np.ones((100, 2), np.float32)
+    ty = np.zeros((100, 2), np.float32)
+    px = (0.2 * np.arange(10)).astype(np.float32)
+    py = np.zeros(10, np.float32)
+    assert oracle_lib.smpc_oracle_find_path_furthest_reached_point(
+        ptr(tx), ptr(ty), 100, 2, ptr(px), ptr(py), 10) == 5
+    assert oracle_lib.smpc_oracle_find_path_trajectory_initial_point(
+        float(tx[0, 0]), float(ty[0, 0]), ptr(px), ptr(py), 10) == 5
+
+
+def test_find_path_costs_kat():
+    """utils_test.cpp:262-323: off-map and lethal points invalid, the rest valid."""
+    o = Oracle(default_config(batch_size=1, time_steps=2))
+    cells = np.zeros((50, 50), np.uint8)
+    cells[10:31, 10:31] = 254        # setCost(i, j): i = x, j = y; the block is square
+    cells[45, 40:46] = 253           # i in 40..45 (x), j = 45 (y)
+    o.set_costmap(cells, 0.0, 0.0, 0.1)
+    px = np.zeros(50, np.float32)
+    py = np.zeros(50, np.float32)
+    px[1] = py[1] = 999999999
+    px[10] = py[10] = 1.5
+    px[20] = py[20] = 4.2
+    valid = np.zeros(49, np.uint8)
+    assert o.lib.smpc_oracle_find_path_costs(o.h, ptr(px), ptr(py), 50, ptr(valid)) == 0
+    for i in range(49):
+        assert bool(valid[i]) == (i not in (1, 10)), i
+    # a point inside the inscribed band is invalid too (utils.hpp:378-380)
+    px[20], py[20] = 4.2, 4.55
+    o.lib.smpc_oracle_find_path_costs(o.h, ptr(px), ptr(py), 50, ptr(valid))
+    assert not valid[20]
+
+
+def test_find_closest_path_pt_quirks(oracle_lib):
+    """utils.hpp:665-675 literal behaviour incl. the `return 0` quirk."""
+    vec = np.array([0.0, 1.0, 2.0, 3.0], np.float32)
+    f = oracle_lib.smpc_oracle_find_closest_path_pt
+    assert f(ptr(vec), 4, 0.0, 0) == 0
+    assert f(ptr(vec), 4, 1.4, 0) == 1
+    assert f(ptr(vec), 4, 1.6, 0) == 2
+    assert f(ptr(vec), 4, 1.5, 0) == 2        # tie goes to the upper point (strict <)
+    assert f(ptr(vec), 4, 2.0, 2) == 0        # iter == begin + init returns 0, not init
+    assert f(ptr(vec), 4, 9.0, 1) == 3        # beyond the end: defined as size-1
+
+
+def test_defaults_match_reference_parameters(oracle_lib):
+    """Parameter defaults: optimizer.cpp:69-82 and each critic's initialize()."""
+    c = A.SmpcConfig()
+    oracle_lib.smpc_config_default(C.byref(c))
+    d = default_config()
+    for name, _ in A.SmpcConfig._fields_:
+        assert getattr(c, name) == getattr(d, name), name
+    assert (c.batch_size, c.time_steps, c.iteration_count) == (1000, 56, 1)
+    p = A.SmpcCriticParams()
+    oracle_lib.smpc_critic_params_default(C.byref(p))
+    q = default_critics()
+    assert bytes(p) == bytes(q)
+    assert p.obstacles.collision_cost == 10000.0 and p.path_align.offset_from_furthest == 20
+    assert p.path_follow.offset_from_furthest == 6 and abs(p.path_follow.threshold_to_consider - 1.4) < 1e-6
