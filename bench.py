@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — rollouts/sec of one Optimizer::optimize() tick on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one computeVelocityCommands() tick's optimize() call through the
+C-ABI (libsmpc.so): per-tick upload (control sequence, plan, tables), the
+kernels, the exchange(s) when N > 1, and the read-back of the new control
+sequence.  The noise tensors and the costmap are resident in HBM before the
+timed region (the reference draws noise once per reset and reuses it,
+src/noise_generator.cpp:26-42).
+
+Workload (weak scaling): every GPU owns 262 144 rollouts x 64 steps on the
+200x200 synthetic costmap — BASELINE.json configs[3] (2 097 152 x 64 on 8 GPUs)
+is exactly the N=8 run; N=1 is its per-GPU shard.  configs[1] (65 536 x 64) and
+configs[2] (262 144 x 128, 2000x2000 map) are timed too at N=1 and reported
+under "other_configs".
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHARD_ROLLOUTS = 262144
+HORIZON = 64
+
+
+def algorithmic_bytes(B, T, W, H, P):
+    """noise read once, cost written+read once, compulsory
+    costmap bytes, path, control sequence in/out."""
+    return B * (12 * T + 8) + min(W * H, B * T) + 12 * P + 24 * T
+
+
+def shift(u):
+    """Optimizer::shiftControlSequence (src/optimizer.cpp:206-225)."""
+    return np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+
+
+def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0):
+    from mpcholonavigation_amd import _abi as A
+    from mpcholonavigation_amd.optimizer import Smpc
+    from mpcholonavigation_amd.synthetic import make_scenario
+    from mpcholonavigation_amd.tick import default_config, default_critics
+    cfg = default_config(batch_size=B, time_steps=T, flags=flags | A.SMPC_FLAG_PROFILE,
+                         shard_offset=shard_offset, global_batch_size=global_batch)
+    scn = make_scenario(T, map_size=map_size)
+    g = Smpc(cfg)
+    g.set_critics(default_critics())
+    g.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution,
+                  inscribed_radius=scn.inscribed_radius,
+                  cost_scaling_factor=scn.cost_scaling_factor,
+                  inflation_radius=scn.inflation_radius)
+    g.seed(seed)     # device RNG fills the stored noise tensors once (HBM resident)
+    return g, scn, cfg
+
+
+def run_ticks(step_fn, scn, steps, warmup, sync, barrier):
+    u = scn.u0
+    for _ in range(warmup):
+        u_new, out = step_fn(scn.tick, u)
+        u = shift(u_new)
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    pass_ms = dev_ms = 0.0
+    passes = 0
+    for _ in range(steps):
+        u_new, out = step_fn(scn.tick, u)
+        u = shift(u_new)
+        pass_ms += out.score_pass_ms
+        dev_ms += out.device_ms
+        passes += out.passes
+    sync()
+    barrier()
+    t1 = time.perf_counter()
+    return (t1 - t0), pass_ms / steps, dev_ms / steps, passes / steps, out
+
+
+def time_config(B, T, map_size, steps, warmup):
+    import torch
+    g, scn, cfg = make_ctx(B, T, map_size)
+    el, pass_ms, dev_ms, passes, out = run_ticks(g.optimize, scn, steps, warmup,
+                                                 torch.cuda.synchronize, lambda: None)
+    P = len(scn.tick.path_x)
+    by = algorithmic_bytes(B, T, map_size, map_size, P)
+    r = {
+        "rollouts_per_s": B * steps / el,
+        "ms_per_tick": 1e3 * el / steps,
+        "score_pass_ms": pass_ms,
+        "device_ms": dev_ms,
+        "algorithmic_bytes": by,
+        "roofline_frac_score_pass": (by / (pass_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if pass_ms else None,
+        "furthest": int(out.furthest_reached_path_point),
+        "passes_per_tick": passes,
+    }
+    g.close()
+    return r
+
+
+def cpu_baseline(T, map_size, budget_s=12.0):
+    """The CPU restatement built with the reference's flags, one thread
+    (the reference is single-threaded: CMakeLists.txt:7-8), bounded sample."""
+    from mpcholonavigation_amd.synthetic import make_noise, make_scenario
+    from mpcholonavigation_amd.tick import default_config, default_critics
+    from oracle.loader import Oracle, build
+    build()
+    B = 65536
+    cfg = default_config(batch_size=B, time_steps=T)
+    scn = make_scenario(T, map_size=map_size)
+    o = Oracle(cfg, fast=True)
+    o.set_critics(default_critics())
+    o.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution,
+                  inscribed_radius=scn.inscribed_radius,
+                  cost_scaling_factor=scn.cost_scaling_factor,
+                  inflation_radius=scn.inflation_radius)
+    o.set_noise(*make_noise(B, T))
+    u = scn.u0
+    u_new, _ = o.optimize(scn.tick, u)     # warm-up tick
+    u = shift(u_new)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        u_new, _ = o.optimize(scn.tick, u)
+        u = shift(u_new)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 200:
+            break
+    el = time.perf_counter() - t0
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": B * n / el, "unit": "rollouts/s", "cores": 1, "kind": "port",
+        "sample": f"{n} ticks of {B} rollouts x {T} steps, {map_size}x{map_size} costmap, "
+                  f"oracle built -O3 -mavx2 -mfma -ffast-math; host {cpu}, "
+                  f"{os.cpu_count()} logical cores present",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rollouts-per-gpu", type=int, default=SHARD_ROLLOUTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--speculate", action="store_true",
+                    help="skip the furthest-point exchange by speculating on the previous tick's value")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, T, MAP = args.rollouts_per_gpu, HORIZON, 200
+    g, scn, cfg = make_ctx(B, T, MAP, shard_offset=rank * B, global_batch=world * B)
+    P = len(scn.tick.path_x)
+
+    if world > 1:
+        from mpcholonavigation_amd.sharded import HipShard, ShardedOptimizer
+        so = ShardedOptimizer(HipShard(g), speculate=args.speculate)
+        step_fn = so.optimize
+
+        def barrier():
+            dist.barrier()
+    else:
+        step_fn = g.optimize
+
+        def barrier():
+            pass
+
+    el, pass_ms, dev_ms, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
+                                                 torch.cuda.synchronize, barrier)
+    if world > 1:
+        t = torch.tensor([el, pass_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, pass_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        by = algorithmic_bytes(B, T, MAP, MAP, P)
+        achieved = by / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        line = {
+            "metric": "rollouts/sec per computeVelocityCommands() tick",
+            "value": world * B * cfg.iteration_count * args.steps / el,
+            "unit": "rollouts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[3] weak-scaled: {B} rollouts x {T} steps per GPU "
+                            f"({world * B} total), full critic stack, 200x200 costmap in LDS, "
+                            "stored noise (HBM resident), iteration_count 1",
+                "rollouts_per_gpu": B, "horizon": T, "costmap": "200x200", "path_points": P,
+                "critics": ["Obstacles", "PathAlign", "PathFollow", "GoalAngle", "PreferForward"],
+                "exchange": ("none" if world == 1 else
+                             ("all_gather(tuple) [speculative furthest]" if args.speculate else
+                              "all_reduce(max furthest) + all_gather(tuple)")) ,
+                "furthest_reached_path_point": int(out.furthest_reached_path_point),
+                "scoring_passes_per_tick": passes,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "smpc_pass<1,0>",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": by,
+                "avg_launch_ms": pass_ms,
+                "device_ms_per_tick": dev_ms,
+            },
+        }
+        if world == 1 and not args.no_other_configs:
+            line["other_configs"] = {
+                "configs[1] 65536x64 200x200": time_config(65536, 64, 200, args.steps, args.warmup),
+                "configs[2] 262144x128 2000x2000": time_config(262144, 128, 2000,
+                                                                max(20, args.steps // 4),
+                                                                max(5, args.warmup // 4)),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(T, MAP)
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,8 @@ extern "C" {
                                              works [ref optimizer.cpp:455-458] */
 #define SMPC_FLAG_NO_SPECULATION 0x2u     /* always run the furthest-point
                                              pre-pass (exact two-pass mode)  */
+#define SMPC_FLAG_PROFILE 0x4u            /* bracket each scoring pass with HIP
+                                             events (smpc_tick_out.score_pass_ms) */
 
 /*
  * Optimizer settings.  Mirrors sortham::models::OptimizerSettings,
@@ -184,7 +186,10 @@ typedef struct smpc_tick_out {
   float sum_w;              /* sum of exp weights of the last iteration            */
   uint32_t passes;          /* scoring passes over the noise (speculation misses
                                show up as passes > iteration_count)               */
-  float device_ms;          /* GPU time of this call's kernels (HIP events)        */
+  float device_ms;          /* GPU time of this call, first upload to last kernel
+                               (HIP events on the ctx's stream)                     */
+  float score_pass_ms;      /* SMPC_FLAG_PROFILE: mean GPU time of one scoring-pass
+                               kernel (smpc_pass) of this call, HIP events around it */
 } smpc_tick_out;
 
 typedef struct smpc_ctx smpc_ctx;
@@ -303,6 +308,11 @@ int smpc_shard_furthest(smpc_ctx* ctx, float* d_furthest);
  * sum w*cvx[T], sum w*cvy[T], sum w*cwz[T]} to d_tuple (device). */
 int smpc_shard_score(smpc_ctx* ctx, const float* d_furthest, uint32_t furthest_hint,
                      float* d_tuple);
+/* After smpc_shard_combine() reported fail_flag = 1 on a tick that did not
+ * start with fail_flag_in: the reference scored no critic past Obstacles
+ * [ref critic_manager.cpp:70-73].  Re-score this shard that way into d_tuple;
+ * the caller gathers and combines again. */
+int smpc_shard_rescore_failed(smpc_ctx* ctx, float* d_tuple);
 /* Combine n_tuples shard tuples (device, contiguous) into the new control
  * sequence: rescale by exp(-(min_g - min)/temperature), divide, clip
  * [ref src/optimizer.cpp:382-393]; copies u (3*T) to host and fills *out.

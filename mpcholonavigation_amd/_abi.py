@@ -24,6 +24,7 @@ SMPC_MODEL_OMNI = 0
 
 SMPC_FLAG_STORE_TRAJECTORIES = 0x1
 SMPC_FLAG_NO_SPECULATION = 0x2
+SMPC_FLAG_PROFILE = 0x4
 
 SMPC_TUPLE_HEADER = 4
 
@@ -150,6 +151,7 @@ class SmpcTickOut(C.Structure):
         ("sum_w", C.c_float),
         ("passes", C.c_uint32),
         ("device_ms", C.c_float),
+        ("score_pass_ms", C.c_float),
     ]
 
 
@@ -181,6 +183,7 @@ PROTOTYPES = {
     "smpc_shard_begin": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p]),
     "smpc_shard_furthest": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_shard_score": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "smpc_shard_rescore_failed": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_shard_combine": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p,
                                      C.POINTER(SmpcTickOut)]),
 }

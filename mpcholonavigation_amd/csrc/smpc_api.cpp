@@ -1,0 +1,968 @@
+// smpc_api.cpp — host side of the C-ABI declared in include/smpc.h.
+//
+// Owns device memory, the per-tick upload block and the launch sequence; does
+// the O(P) host work the reference's critics do once per tick (goal-distance
+// gates, path validity, cumulative path lengths, the per-candidate PathAlign /
+// PathFollow tables) and the 256-entry Obstacles lookup table.  All [B,T] work
+// is in smpc_kernels.hip.  There is no CPU fallback: without a HIP device
+// smpc_create() fails.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/smpc.h"
+#include "smpc_dev.h"
+
+hipError_t smpc_launch_pass(int R, bool furthest_only, const SmpcDev& p, const SmpcLds& L,
+                            uint32_t grid, uint32_t block, hipStream_t st);
+hipError_t smpc_set_pass_lds_limit(int bytes);
+hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
+                              float neg_inv_temp, float* tuple, hipStream_t st);
+hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, float neg_inv_temp,
+                               float vx_max, float vx_min, float vy_max, float wz_max,
+                               float* u_out, float* result, const float* furthest_used,
+                               hipStream_t st);
+hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
+                                  uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint32_t kBlock = 512;          // threads per block of the streaming pass
+constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
+constexpr uint32_t kWindowBytes = 65536;  // costmap window staged in LDS
+constexpr uint32_t kLdsPerCu = 160 * 1024;
+
+inline uint32_t align_up(uint32_t v, uint32_t a) {return (v + a - 1) / a * a;}
+
+struct HostCostmap {
+  std::vector<uint8_t> cells;
+  uint32_t W = 0, H = 0;
+  double ox = 0, oy = 0, res = 1;
+  bool track_unknown = false;
+  float inscribed_radius = 0, cost_scaling_factor = 0, inflation_radius = 0;
+  bool set = false;
+};
+
+// Costmap2D::worldToMap (nav2_costmap_2d, Humble); call sites tools/utils.hpp:365-372
+inline bool world_to_map(const HostCostmap& c, double wx, double wy, unsigned& mx, unsigned& my)
+{
+  if (wx < c.ox || wy < c.oy) return false;
+  const double qx = (wx - c.ox) / c.res, qy = (wy - c.oy) / c.res;
+  if (!(qx < 4294967296.0) || !(qy < 4294967296.0)) return false;
+  mx = static_cast<unsigned>(qx);
+  my = static_cast<unsigned>(qy);
+  return mx < c.W && my < c.H;
+}
+
+// utils::withinPositionGoalTolerance(float, Pose, Pose) (tools/utils.hpp:233-249)
+inline bool within_tol(float tol, double rx, double ry, double gx, double gy)
+{
+  const double dist_sq = std::pow(gx - rx, 2) + std::pow(gy - ry, 2);
+  const float tol_sq = tol * tol;
+  return dist_sq < tol_sq;
+}
+
+}  // namespace
+
+struct smpc_ctx {
+  smpc_config cfg{};
+  smpc_critic_params critics{};
+  float c_vx_max = 0, c_vx_min = 0, c_vy = 0, c_wz = 0;
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evp[8] = {};   // SMPC_FLAG_PROFILE: pairs around up to 4 scoring passes
+  uint32_t evp_used = 0;
+  // tensors
+  float* d_nvx = nullptr;
+  float* d_nvy = nullptr;
+  float* d_nwz = nullptr;
+  float* d_costs[2] = {nullptr, nullptr};
+  float* d_traj[3] = {nullptr, nullptr, nullptr};
+  int costs_cur = 0;
+  bool have_noise = false, rng_mode = false;
+  uint64_t seed = 0;
+  uint32_t epoch = 0;
+  // costmap
+  HostCostmap map;
+  uint8_t* d_map = nullptr;
+  size_t d_map_bytes = 0;
+  // per-tick block
+  uint8_t* d_tick = nullptr;
+  uint8_t* h_tick = nullptr;  // pinned
+  size_t tick_cap = 0;
+  // reductions / outputs
+  float* d_partials = nullptr;
+  float* d_tuple = nullptr;
+  float* d_out = nullptr;       // [3T u][8 result]
+  float* h_out = nullptr;       // pinned mirror
+  float* d_furthest = nullptr;  // one float (atomicMax on its bits)
+  // launch geometry
+  int R = 1;
+  uint32_t grid = 0;
+  SmpcLds lds{};
+  // per-tick prepared state
+  SmpcDev dev{};
+  uint32_t gate_flags = 0;   // critics past their host-side gates this tick
+  bool tick_ready = false;
+  bool fail_in = false;
+  uint32_t P = 0;
+  uint32_t passes = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(smpc_ctx* c, int code, const std::string& msg)
+{
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCK(ctx, call)                                                               \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return fail(ctx, SMPC_ERR_DEVICE,                                                \
+                  std::string(#call) + ": " + hipGetErrorString(e__));                \
+  } while (0)
+
+void free_ctx(smpc_ctx* c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (float* p : {c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
+         c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
+    if (p) (void)hipFree(p);
+  if (c->d_map) (void)hipFree(c->d_map);
+  if (c->d_tick) (void)hipFree(c->d_tick);
+  if (c->h_tick) (void)hipHostFree(c->h_tick);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->evp) if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+// tick block layout (offsets in bytes), sized for the ctx's T and SMPC_MAX_PATH
+struct TickLayout {
+  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, lut, total;
+};
+TickLayout tick_layout(uint32_t T, uint32_t P)
+{
+  TickLayout l{};
+  size_t o = 0;
+  l.u = o; o += align_up(3 * T * 4, 16);
+  l.px = o; o += align_up(P * 4, 16);
+  l.py = o; o += align_up(P * 4, 16);
+  l.pyaw = o; o += align_up(P * 4, 16);
+  l.D = o; o += align_up(P * 4, 16);
+  l.pf_idx = o; o += align_up(P * 4, 16);
+  l.pvalid = o; o += align_up(P, 16);
+  l.pa_active = o; o += align_up(P, 16);
+  l.lut = o; o += 256 * sizeof(SmpcLut);
+  l.total = o;
+  return l;
+}
+
+// LDS carve-up of the streaming pass
+SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map)
+{
+  SmpcLds L{};
+  uint32_t o = with_map ? align_up(window_bytes, 16) : 0;
+  L.off_lut = o; o += with_map ? 256 * sizeof(SmpcLut) : 0;
+  const uint32_t pf = align_up(std::max(P, 1u) * 4, 16);
+  L.off_px = o; o += pf;
+  L.off_py = o; o += pf;
+  L.off_pyaw = o; o += pf;
+  L.off_D = o; o += pf;
+  L.off_valid = o; o += align_up(std::max(P, 1u), 16);
+  L.off_scr = o;
+  L.scr_stride = align_up(4 + 3 * T, 4);
+  o += nwave * L.scr_stride * 4;
+  L.total = o;
+  return L;
+}
+
+// distanceToObstacle (obstacles_critic.cpp:99-112) for an 8-bit cost, point mode
+float distance_to_obstacle(const HostCostmap& m, float cost)
+{
+  const float scale_factor = m.cost_scaling_factor;
+  const float min_radius = m.inscribed_radius;
+  float d = static_cast<float>(
+    (static_cast<double>(scale_factor * min_radius) - std::log(static_cast<double>(cost)) +
+    std::log(static_cast<double>(253.0f))) / static_cast<double>(scale_factor));
+  d -= min_radius;
+  return d;
+}
+
+void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut)
+{
+  const auto& m = c->map;
+  const auto& p = c->critics.obstacles;
+  for (int v = 0; v < 256; ++v) {
+    lut[v].crit = 0.f;
+    lut[v].rep = 0.f;
+    if (v < 1) continue;                                     // :150 free space
+    if (m.inflation_radius == 0.0f || m.cost_scaling_factor == 0.0f) continue;  // :155
+    const float d = distance_to_obstacle(m, static_cast<float>(v));
+    if (d < p.collision_margin_distance) {
+      lut[v].crit = p.collision_margin_distance - d;         // :165
+    } else if (!near_goal) {
+      lut[v].rep = m.inflation_radius - d;                   // :167
+    }
+  }
+}
+
+int check_tick(smpc_ctx* c, const smpc_tick_in* in)
+{
+  if (!c || !in) return SMPC_ERR_INVALID;
+  if (!c->have_noise) return fail(c, SMPC_ERR_STATE, "no noise: call smpc_set_noise or smpc_seed");
+  if (in->path_len > 0 && (!in->path_x || !in->path_y || !in->path_yaw))
+    return fail(c, SMPC_ERR_INVALID, "path arrays missing");
+  if (in->path_len > SMPC_MAX_PATH)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "path longer than SMPC_MAX_PATH (1024) points");
+  if (!c->map.set && (c->critics.obstacles.enabled || !in->path_pts_valid))
+    return fail(c, SMPC_ERR_STATE, "no costmap: call smpc_set_costmap");
+  if (c->critics.obstacles.consider_footprint)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
+  return SMPC_OK;
+}
+
+// Everything the reference's critics decide once per tick on the host, plus the
+// upload of the tick block.  Leaves c->dev ready for the launches.
+int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
+{
+  int rc = check_tick(c, in);
+  if (rc != SMPC_OK) return rc;
+  if (!u_in) return fail(c, SMPC_ERR_INVALID, "control sequence missing");
+  const uint32_t T = c->cfg.time_steps, B = c->cfg.batch_size, P = in->path_len;
+  const auto& cr = c->critics;
+  HIPCK(c, hipSetDevice(c->device));
+
+  const TickLayout tl = tick_layout(T, std::max(P, 1u));
+  if (tl.total > c->tick_cap) return fail(c, SMPC_ERR_INVALID, "tick block overflow");
+  uint8_t* h = c->h_tick;
+  memcpy(h + tl.u, u_in, 3 * T * sizeof(float));
+  float* px = reinterpret_cast<float*>(h + tl.px);
+  float* py = reinterpret_cast<float*>(h + tl.py);
+  float* pyaw = reinterpret_cast<float*>(h + tl.pyaw);
+  float* D = reinterpret_cast<float*>(h + tl.D);
+  uint32_t* pf_idx = reinterpret_cast<uint32_t*>(h + tl.pf_idx);
+  uint8_t* pvalid = h + tl.pvalid;
+  uint8_t* pa_active = h + tl.pa_active;
+  if (P) {
+    memcpy(px, in->path_x, P * 4);
+    memcpy(py, in->path_y, P * 4);
+    memcpy(pyaw, in->path_yaw, P * 4);
+  }
+
+  // ---- host-side gates: one withinPositionGoalTolerance per critic
+  const double rx = in->pose_x, ry = in->pose_y, gx = in->goal_x, gy = in->goal_y;
+  uint32_t gates = 0;
+  if (cr.obstacles.enabled) gates |= SD_OBSTACLES;
+  if (cr.path_align.enabled && !within_tol(cr.path_align.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_ALIGN;                                   // path_align_critic.cpp:49-54
+  if (cr.path_follow.enabled && P >= 2 &&
+    !within_tol(cr.path_follow.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_FOLLOW;                                  // path_follow_critic.cpp:37-42
+  if (cr.goal_angle.enabled && P >= 1 &&
+    within_tol(cr.goal_angle.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_GOAL_ANGLE;                                   // goal_angle_critic.cpp:38-43
+  if (cr.prefer_forward.enabled &&
+    !within_tol(cr.prefer_forward.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PREFER_FORWARD;                               // prefer_forward_critic.cpp:36-41
+  if (P == 0) gates &= ~(SD_PATH_ALIGN | SD_PATH_FOLLOW);
+  uint32_t nsamp = 0;
+  const uint32_t step = cr.path_align.trajectory_point_step;
+  if (gates & SD_PATH_ALIGN) {
+    nsamp = step > 0 ? (T - 1) / step : 0;
+    if (nsamp > 64)
+      return fail(c, SMPC_ERR_UNSUPPORTED,
+                  "PathAlign: more than 64 samples per trajectory (time_steps / trajectory_point_step)");
+    if (nsamp == 0) gates &= ~SD_PATH_ALIGN;  // no samples: cost 0 for every rollout
+    if (cr.path_align.use_path_orientations) gates |= SD_USE_PATH_YAW;
+  }
+  if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW)) gates |= SD_NEED_FURTHEST;
+  if (c->map.track_unknown) gates |= SD_TRACK_UNKNOWN;
+  if (c->cfg.flags & SMPC_FLAG_STORE_TRAJECTORIES) gates |= SD_STORE_TRAJ;
+
+  // ---- path validity (utils::findPathCosts, tools/utils.hpp:361-395) ----------
+  const uint32_t nseg = P > 0 ? P - 1 : 0;
+  if (in->path_pts_valid) {
+    memcpy(pvalid, in->path_pts_valid, nseg);
+  } else if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW)) {
+    for (uint32_t i = 0; i < nseg; ++i) {
+      unsigned mx, my;
+      uint8_t v = 1;
+      if (!world_to_map(c->map, px[i], py[i], mx, my)) {
+        v = 0;
+      } else {
+        const uint8_t cost = c->map.cells[static_cast<size_t>(my) * c->map.W + mx];
+        if (cost == SMPC_COST_LETHAL || cost == SMPC_COST_INSCRIBED) v = 0;
+        else if (cost == SMPC_COST_NO_INFORMATION) v = c->map.track_unknown ? 1 : 0;
+      }
+      pvalid[i] = v;
+    }
+  } else {
+    memset(pvalid, 0, std::max(nseg, 1u));
+  }
+
+  // ---- PathAlign: cumulative path lengths (path_align_critic.cpp:82-90) --------
+  if (nseg) {
+    D[0] = 0.0f;
+    for (uint32_t i = 1; i < nseg; ++i) {
+      const float dx = px[i] - px[i - 1];
+      const float dy = py[i] - py[i - 1];
+      D[i] = D[i - 1] + sqrtf(dx * dx + dy * dy);
+    }
+  }
+
+  // ---- per-candidate-furthest-point tables -------------------------------------
+  const float yaw0 = in->pose_yaw;
+  const float cos0 = cosf(yaw0), sin0 = sinf(yaw0);
+  const float svx = static_cast<float>(in->speed_vx);
+  const float svy = static_cast<float>(in->speed_vy);
+  const float swz = static_cast<float>(in->speed_wz);
+  const float dt = c->cfg.model_dt;
+  if (gates & SD_PATH_ALIGN) {
+    // trajectories(0,0): first rollout point, identical for every rollout because
+    // v[:,0] is the measured speed (optimizer.cpp:258-267,331-342)
+    const float dx0 = svx * cos0 - svy * sin0;
+    const float dy0 = svx * sin0 + svy * cos0;
+    const float x00 = static_cast<float>(in->pose_x + static_cast<double>(dx0 * dt));
+    const float y00 = static_cast<float>(in->pose_y + static_cast<double>(dy0 * dt));
+    // utils::findPathTrajectoryInitialPoint (tools/utils.hpp:327-344)
+    size_t init = 0;
+    float best = std::numeric_limits<float>::max();
+    for (uint32_t j = 0; j < P; ++j) {
+      const float ddx = px[j] - x00, ddy = py[j] - y00;
+      const float d = ddx * ddx + ddy * ddy;
+      if (d < best) {
+        best = d;
+        init = j;
+      }
+    }
+    for (uint32_t S = 0; S < P; ++S) {
+      bool on = S >= cr.path_align.offset_from_furthest;     // path_align_critic.cpp:58-61
+      if (on) {
+        // :64-74 occupancy of the path between the initial and the furthest point
+        unsigned int invalid_ctr = 0;
+        const float range = static_cast<float>(static_cast<size_t>(S) - init);
+        for (size_t i = init; i < S; i++) {
+          if (!pvalid[i]) invalid_ctr++;
+          if (static_cast<float>(invalid_ctr) / range > cr.path_align.max_path_occupancy_ratio &&
+            invalid_ctr > 2)
+          {
+            on = false;
+            break;
+          }
+        }
+      }
+      pa_active[S] = on ? 1 : 0;
+    }
+  } else {
+    memset(pa_active, 0, std::max(P, 1u));
+  }
+  if (gates & SD_PATH_FOLLOW) {
+    // path_follow_critic.cpp:46-57
+    const size_t path_size = P - 1;
+    for (uint32_t S = 0; S < P; ++S) {
+      size_t idx = std::min(static_cast<size_t>(S) + cr.path_follow.offset_from_furthest, path_size);
+      bool valid = false;
+      while (!valid && idx < path_size - 1) {
+        valid = pvalid[idx];
+        if (!valid) idx++;
+      }
+      pf_idx[S] = static_cast<uint32_t>(idx);
+    }
+  } else {
+    memset(pf_idx, 0, std::max(P, 1u) * 4);
+  }
+
+  // ---- Obstacles LUT -------------------------------------------------------------
+  SmpcLut* lut = reinterpret_cast<SmpcLut*>(h + tl.lut);
+  if (gates & SD_OBSTACLES) {
+    const bool near_goal = within_tol(cr.obstacles.near_goal_distance, rx, ry, gx, gy);  // :124-127
+    build_lut(c, near_goal, lut);
+  } else {
+    memset(lut, 0, 256 * sizeof(SmpcLut));
+  }
+
+  HIPCK(c, hipEventRecord(c->ev0, c->stream));
+  HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
+
+  // ---- kernel parameter block ------------------------------------------------------
+  SmpcDev& d = c->dev;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.T = T; d.P = P; d.nsamp = nsamp; d.step = step;
+  d.x0 = in->pose_x; d.y0 = in->pose_y;
+  d.yaw0 = yaw0; d.cos0 = cos0; d.sin0 = sin0;
+  d.svx = svx; d.svy = svy; d.swz = swz; d.dt = dt;
+  d.nvx = c->d_nvx; d.nvy = c->d_nvy; d.nwz = c->d_nwz;
+  d.u = reinterpret_cast<const float*>(c->d_tick + tl.u);
+  d.traj_x = c->d_traj[0]; d.traj_y = c->d_traj[1]; d.traj_yaw = c->d_traj[2];
+  d.map = c->d_map; d.W = c->map.W; d.H = c->map.H;
+  d.ox = c->map.ox; d.oy = c->map.oy; d.res = c->map.res;
+  d.lut = reinterpret_cast<const SmpcLut*>(c->d_tick + tl.lut);
+  d.px = reinterpret_cast<const float*>(c->d_tick + tl.px);
+  d.py = reinterpret_cast<const float*>(c->d_tick + tl.py);
+  d.pyaw = reinterpret_cast<const float*>(c->d_tick + tl.pyaw);
+  d.D = reinterpret_cast<const float*>(c->d_tick + tl.D);
+  d.pvalid = c->d_tick + tl.pvalid;
+  d.pa_active = c->d_tick + tl.pa_active;
+  d.pf_idx = reinterpret_cast<const uint32_t*>(c->d_tick + tl.pf_idx);
+  d.obs_critical_w = cr.obstacles.critical_weight;
+  d.obs_repulsion_w = cr.obstacles.repulsion_weight;
+  d.obs_collision_cost = cr.obstacles.collision_cost;
+  d.obs_power = cr.obstacles.cost_power;
+  d.pa_weight = cr.path_align.cost_weight; d.pa_power = cr.path_align.cost_power;
+  d.pf_weight = cr.path_follow.cost_weight; d.pf_power = cr.path_follow.cost_power;
+  d.ga_weight = cr.goal_angle.cost_weight; d.ga_power = cr.goal_angle.cost_power;
+  d.ga_goal_yaw = P ? pyaw[P - 1] : 0.f;
+  d.pfw_weight = cr.prefer_forward.cost_weight; d.pfw_power = cr.prefer_forward.cost_power;
+  d.g_vx = c->cfg.gamma / powf(c->cfg.vx_std, 2);
+  d.g_vy = c->cfg.gamma / powf(c->cfg.vy_std, 2);
+  d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
+  d.neg_inv_temp = -1 / c->cfg.temperature;
+  d.partials = c->d_partials;
+  d.furthest_out = reinterpret_cast<uint32_t*>(c->d_furthest);
+
+  // ---- costmap window staged in LDS, centred on the robot ---------------------------
+  uint32_t window_bytes = 0;
+  if (c->map.set && (gates & SD_OBSTACLES)) {
+    uint32_t side = 4;
+    while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 256 for 64 KiB
+    const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
+    long cx = static_cast<long>((in->pose_x - c->map.ox) / c->map.res);
+    long cy = static_cast<long>((in->pose_y - c->map.oy) / c->map.res);
+    long wx0 = cx - ww / 2, wy0 = cy - wh / 2;
+    wx0 = std::max(0L, std::min(wx0, static_cast<long>(c->map.W) - static_cast<long>(ww)));
+    wy0 = std::max(0L, std::min(wy0, static_cast<long>(c->map.H) - static_cast<long>(wh)));
+    wx0 &= ~3L;
+    d.win_x0 = static_cast<int32_t>(wx0); d.win_y0 = static_cast<int32_t>(wy0);
+    d.win_w = static_cast<int32_t>(ww); d.win_h = static_cast<int32_t>(wh);
+    window_bytes = ww * wh;
+  }
+  c->lds = make_lds(window_bytes, P, T, kBlock / 64, window_bytes != 0);
+  if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
+
+  // persistent grid: as many blocks as stay resident, never more than the work
+  const uint32_t waves_per_block = kBlock / 64;
+  uint32_t by_lds = std::max(1u, kLdsPerCu / std::max(c->lds.total, 1u));
+  uint32_t per_cu = std::min(by_lds, 32u / waves_per_block);
+  uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
+                           static_cast<uint32_t>(c->num_cu) * per_cu);
+  c->grid = std::max(1u, std::min(grid, kMaxGrid));
+
+  c->gate_flags = gates;
+  c->fail_in = in->fail_flag_in != 0;
+  c->P = P;
+  c->tick_ready = true;
+  return SMPC_OK;
+}
+
+int launch_furthest(smpc_ctx* c, float* d_furthest)
+{
+  HIPCK(c, hipMemsetAsync(d_furthest, 0, sizeof(float), c->stream));
+  SmpcDev d = c->dev;
+  d.flags = c->gate_flags & SD_NEED_FURTHEST;
+  d.furthest_out = reinterpret_cast<uint32_t*>(d_furthest);
+  SmpcLds L = make_lds(0, c->P, d.T, kBlock / 64, false);
+  HIPCK(c, smpc_launch_pass(c->R, true, d, L, c->grid, kBlock, c->stream));
+  return SMPC_OK;
+}
+
+// one scoring pass + block reduction -> tuple
+int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
+                 uint32_t furthest_hint, float* d_tuple)
+{
+  SmpcDev d = c->dev;
+  d.flags = flags;
+  if (u_dev) d.u = u_dev;
+  d.d_furthest = d_furthest;
+  d.furthest_hint = furthest_hint;
+  d.costs = c->d_costs[c->costs_cur];
+  d.costs_prev = c->d_costs[c->costs_cur ^ 1];
+  const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
+  if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
+  HIPCK(c, smpc_launch_pass(c->R, false, d, c->lds, c->grid, kBlock, c->stream));
+  if (prof) {
+    HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
+    c->evp_used += 2;
+  }
+  HIPCK(c, smpc_launch_reduce(c->d_partials, c->grid, d.T, d.neg_inv_temp, d_tuple, c->stream));
+  c->passes++;
+  return SMPC_OK;
+}
+
+int launch_combine(smpc_ctx* c, const float* d_tuples, uint32_t n, const float* d_furthest_used)
+{
+  const uint32_t T = c->cfg.time_steps;
+  HIPCK(c, smpc_launch_combine(d_tuples, n, T, c->dev.neg_inv_temp, c->c_vx_max, c->c_vx_min,
+                               c->c_vy, c->c_wz, c->d_out, c->d_out + 3 * T, d_furthest_used,
+                               c->stream));
+  return SMPC_OK;
+}
+
+int fetch_out(smpc_ctx* c)
+{
+  const uint32_t T = c->cfg.time_steps;
+  HIPCK(c, hipMemcpyAsync(c->h_out, c->d_out, (3 * T + 8) * sizeof(float), hipMemcpyDeviceToHost,
+                          c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return SMPC_OK;
+}
+
+float profile_pass_ms(smpc_ctx* c)
+{
+  float sum = 0.f;
+  uint32_t n = 0;
+  for (uint32_t i = 0; i + 1 < c->evp_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->evp[i], c->evp[i + 1]) == hipSuccess) {
+      sum += ms;
+      n++;
+    }
+  }
+  return n ? sum / n : 0.f;
+}
+
+uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky)
+{
+  // CriticManager::evalTrajectoriesScores breaks on fail_flag (critic_manager.cpp:70-73)
+  const uint32_t keep = SD_STORE_TRAJ | SD_TRACK_UNKNOWN;
+  return fail_sticky ? (c->gate_flags & keep) : c->gate_flags;
+}
+
+int draw_noise(smpc_ctx* c)
+{
+  const uint64_t n = static_cast<uint64_t>(c->cfg.batch_size) * c->cfg.time_steps;
+  const uint64_t base = c->cfg.shard_offset * c->cfg.time_steps;
+  // draw order vx, wz, vy (noise_generator.cpp:107-122)
+  HIPCK(c, smpc_launch_fill_noise(c->d_nvx, n, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
+  HIPCK(c, smpc_launch_fill_noise(c->d_nwz, n, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
+  HIPCK(c, smpc_launch_fill_noise(c->d_nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  c->have_noise = true;
+  return SMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void smpc_config_default(smpc_config* c)
+{
+  memset(c, 0, sizeof(*c));
+  c->batch_size = 1000;   // ref src/optimizer.cpp:69-82
+  c->time_steps = 56;
+  c->iteration_count = 1;
+  c->motion_model = SMPC_MODEL_OMNI;
+  c->model_dt = 0.05f;
+  c->temperature = 0.3f;
+  c->gamma = 0.015f;
+  c->vx_max = 0.5f;
+  c->vx_min = -0.35f;
+  c->vy_max = 0.5f;
+  c->wz_max = 1.9f;
+  c->vx_std = 0.2f;
+  c->vy_std = 0.2f;
+  c->wz_std = 0.4f;
+  c->device = -1;
+}
+
+void smpc_critic_params_default(smpc_critic_params* p)
+{
+  memset(p, 0, sizeof(*p));
+  p->obstacles = {1, 0, 1, 1.5f, 20.0f, 10000.0f, 0.10f, 0.5f};
+  p->path_align = {1, 0, 1, 10.0f, 0.07f, 20, 4, 0.5f};
+  p->path_follow = {1, 1, 5.0f, 1.4f, 6};
+  p->goal_angle = {1, 1, 3.0f, 0.5f};
+  p->prefer_forward = {1, 1, 5.0f, 0.5f};
+}
+
+int smpc_abi_version(void) {return SMPC_ABI_VERSION;}
+
+const char* smpc_build_info(void)
+{
+  return "libsmpc (MI355X-native sampling-MPC hot path), HIP gfx950, built " __DATE__ " " __TIME__;
+}
+
+const char* smpc_last_error(const smpc_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int smpc_create(const smpc_config* cfg, smpc_ctx** out)
+{
+  if (!cfg || !out) return fail(nullptr, SMPC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->batch_size == 0 || cfg->time_steps == 0 || cfg->iteration_count == 0)
+    return fail(nullptr, SMPC_ERR_INVALID, "batch_size, time_steps, iteration_count must be > 0");
+  if (cfg->motion_model != SMPC_MODEL_OMNI)
+    return fail(nullptr, SMPC_ERR_UNSUPPORTED, "only the Omni (holonomic) motion model is in scope");
+  if (cfg->time_steps > 64 * SMPC_MAX_R)
+    return fail(nullptr, SMPC_ERR_UNSUPPORTED, "time_steps > 256");
+  if (!(cfg->temperature > 0.f) || !(cfg->model_dt > 0.f))
+    return fail(nullptr, SMPC_ERR_INVALID, "temperature and model_dt must be > 0");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, SMPC_ERR_DEVICE,
+                std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                " (libsmpc has no CPU fallback)");
+  smpc_ctx* c = new (std::nothrow) smpc_ctx();
+  if (!c) return fail(nullptr, SMPC_ERR_NOMEM, "out of host memory");
+  c->cfg = *cfg;
+  smpc_critic_params_default(&c->critics);
+  c->c_vx_max = cfg->vx_max; c->c_vx_min = cfg->vx_min; c->c_vy = cfg->vy_max; c->c_wz = cfg->wz_max;
+  int dev = cfg->device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  }
+  c->device = dev;
+#define CK(call)                                                                        \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      g_create_error = std::string(#call) + ": " + hipGetErrorString(e__);              \
+      free_ctx(c);                                                                      \
+      return SMPC_ERR_DEVICE;                                                           \
+    }                                                                                   \
+  } while (0)
+  CK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, dev));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  CK(hipEventCreate(&c->ev0));
+  CK(hipEventCreate(&c->ev1));
+  if (cfg->flags & SMPC_FLAG_PROFILE) for (auto& e : c->evp) CK(hipEventCreate(&e));
+  const uint32_t T = cfg->time_steps;
+  c->R = T <= 64 ? 1 : (T <= 128 ? 2 : 4);
+  const size_t n = static_cast<size_t>(cfg->batch_size) * T * sizeof(float);
+  CK(hipMalloc(&c->d_nvx, n));
+  CK(hipMalloc(&c->d_nvy, n));
+  CK(hipMalloc(&c->d_nwz, n));
+  CK(hipMalloc(&c->d_costs[0], cfg->batch_size * sizeof(float)));
+  CK(hipMalloc(&c->d_costs[1], cfg->batch_size * sizeof(float)));
+  CK(hipMemset(c->d_costs[0], 0, cfg->batch_size * sizeof(float)));
+  CK(hipMemset(c->d_costs[1], 0, cfg->batch_size * sizeof(float)));
+  if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) {
+    for (int i = 0; i < 3; ++i) {
+      CK(hipMalloc(&c->d_traj[i], n));
+      CK(hipMemset(c->d_traj[i], 0, n));
+    }
+  }
+  c->tick_cap = tick_layout(T, SMPC_MAX_PATH).total;
+  CK(hipMalloc(&c->d_tick, c->tick_cap));
+  CK(hipHostMalloc(&c->h_tick, c->tick_cap, hipHostMallocDefault));
+  const size_t TL = 4 + 3 * static_cast<size_t>(T);
+  CK(hipMalloc(&c->d_partials, kMaxGrid * TL * sizeof(float)));
+  CK(hipMalloc(&c->d_tuple, TL * sizeof(float)));
+  CK(hipMalloc(&c->d_out, (3 * T + 8) * sizeof(float)));
+  CK(hipHostMalloc(&c->h_out, (3 * T + 8) * sizeof(float), hipHostMallocDefault));
+  CK(hipMalloc(&c->d_furthest, 16));
+  CK(hipMemset(c->d_furthest, 0, 16));
+  CK(smpc_set_pass_lds_limit(static_cast<int>(kLdsPerCu)));
+#undef CK
+  *out = c;
+  return SMPC_OK;
+}
+
+void smpc_destroy(smpc_ctx* ctx) {free_ctx(ctx);}
+
+int smpc_reset(smpc_ctx* c)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  HIPCK(c, hipSetDevice(c->device));
+  // Optimizer::reset (optimizer.cpp:116-132): constraints back to base, costs zero,
+  // NoiseGenerator::reset re-draws (noise_generator.cpp:76-95)
+  c->c_vx_max = c->cfg.vx_max; c->c_vx_min = c->cfg.vx_min;
+  c->c_vy = c->cfg.vy_max; c->c_wz = c->cfg.wz_max;
+  HIPCK(c, hipMemsetAsync(c->d_costs[0], 0, c->cfg.batch_size * sizeof(float), c->stream));
+  HIPCK(c, hipMemsetAsync(c->d_costs[1], 0, c->cfg.batch_size * sizeof(float), c->stream));
+  c->tick_ready = false;
+  if (c->rng_mode) {
+    c->epoch++;
+    return draw_noise(c);
+  }
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return SMPC_OK;
+}
+
+int smpc_set_constraints(smpc_ctx* c, float vx_max, float vx_min, float vy_max, float wz_max)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  c->c_vx_max = vx_max; c->c_vx_min = vx_min; c->c_vy = vy_max; c->c_wz = wz_max;
+  return SMPC_OK;
+}
+
+int smpc_set_critics(smpc_ctx* c, const smpc_critic_params* p)
+{
+  if (!c || !p) return SMPC_ERR_INVALID;
+  if (p->obstacles.enabled && p->obstacles.consider_footprint)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
+  c->critics = *p;
+  return SMPC_OK;
+}
+
+int smpc_set_costmap(smpc_ctx* c, const uint8_t* cells, uint32_t width, uint32_t height,
+                     double origin_x, double origin_y, double resolution, int track_unknown,
+                     float inscribed_radius, float cost_scaling_factor, float inflation_radius)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (!cells || width == 0 || height == 0 || !(resolution > 0.0))
+    return fail(c, SMPC_ERR_INVALID, "bad costmap");
+  HIPCK(c, hipSetDevice(c->device));
+  const size_t bytes = static_cast<size_t>(width) * height;
+  if (bytes > c->d_map_bytes) {
+    if (c->d_map) HIPCK(c, hipFree(c->d_map));
+    c->d_map = nullptr;
+    HIPCK(c, hipMalloc(&c->d_map, (bytes + 255) / 256 * 256));
+    c->d_map_bytes = bytes;
+  }
+  HostCostmap& m = c->map;
+  m.cells.assign(cells, cells + bytes);
+  m.W = width; m.H = height; m.ox = origin_x; m.oy = origin_y; m.res = resolution;
+  m.track_unknown = track_unknown != 0;
+  m.inscribed_radius = inscribed_radius;
+  m.cost_scaling_factor = cost_scaling_factor;
+  m.inflation_radius = inflation_radius;
+  m.set = true;
+  HIPCK(c, hipMemcpyAsync(c->d_map, m.cells.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return SMPC_OK;
+}
+
+int smpc_set_noise(smpc_ctx* c, const float* nvx, const float* nvy, const float* nwz)
+{
+  if (!c || !nvx || !nvy || !nwz) return SMPC_ERR_INVALID;
+  HIPCK(c, hipSetDevice(c->device));
+  const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
+  HIPCK(c, hipMemcpyAsync(c->d_nvx, nvx, n, hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(c->d_nvy, nvy, n, hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(c->d_nwz, nwz, n, hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  c->have_noise = true;
+  c->rng_mode = false;
+  return SMPC_OK;
+}
+
+int smpc_seed(smpc_ctx* c, uint64_t seed)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  HIPCK(c, hipSetDevice(c->device));
+  c->seed = seed;
+  c->epoch = 0;
+  c->rng_mode = true;
+  return draw_noise(c);
+}
+
+int smpc_get_noise(smpc_ctx* c, float* nvx, float* nvy, float* nwz)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (!c->have_noise) return fail(c, SMPC_ERR_STATE, "no noise yet");
+  HIPCK(c, hipSetDevice(c->device));
+  const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  if (nvx) HIPCK(c, hipMemcpy(nvx, c->d_nvx, n, hipMemcpyDeviceToHost));
+  if (nvy) HIPCK(c, hipMemcpy(nvy, c->d_nvy, n, hipMemcpyDeviceToHost));
+  if (nwz) HIPCK(c, hipMemcpy(nwz, c->d_nwz, n, hipMemcpyDeviceToHost));
+  return SMPC_OK;
+}
+
+int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick_out* out)
+{
+  if (!c || !in || !u_inout) return fail(c, SMPC_ERR_INVALID, "null argument");
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = prepare_tick(c, in, u_inout);
+  if (rc != SMPC_OK) return rc;
+  const uint32_t T = c->cfg.time_steps;
+  c->passes = 0;
+  c->evp_used = 0;
+  c->costs_cur = 0;
+  bool fail_sticky = c->fail_in;
+  bool furthest_cached = false;
+  bool fail_flag = fail_sticky;
+  bool fetched = false;
+  const bool need_f = (c->gate_flags & SD_NEED_FURTHEST) != 0;
+  for (uint32_t it = 0; it < c->cfg.iteration_count; ++it) {
+    uint32_t flags = scoring_flags(c, fail_sticky);
+    if (it > 0) flags |= SD_ACCUMULATE;
+    const float* u_dev = it == 0 ? nullptr : c->d_out;
+    c->costs_cur = it & 1;
+    if ((flags & SD_NEED_FURTHEST) && !furthest_cached) {
+      // setPathFurthestPointIfNotSet: evaluated once per tick (utils.hpp:350-355, H3)
+      rc = launch_furthest(c, c->d_furthest);
+      if (rc != SMPC_OK) return rc;
+      furthest_cached = true;
+    }
+    rc = launch_score(c, flags, u_dev, (flags & SD_NEED_FURTHEST) ? c->d_furthest : nullptr, 0,
+                      c->d_tuple);
+    if (rc != SMPC_OK) return rc;
+    rc = launch_combine(c, c->d_tuple, 1, furthest_cached ? c->d_furthest : nullptr);
+    if (rc != SMPC_OK) return rc;
+    HIPCK(c, hipEventRecord(c->ev1, c->stream));
+    fetched = false;
+    if (flags & SD_OBSTACLES) {
+      // fail_flag = all trajectories collide (obstacles_critic.cpp:177) decides what the
+      // remaining critics and iterations may do: one host round trip (it is also the
+      // final read-back when this is the last iteration)
+      rc = fetch_out(c);
+      if (rc != SMPC_OK) return rc;
+      fetched = true;
+      if (c->h_out[3 * T + 3] == 0.0f) {
+        // the critics after Obstacles were not scored in the reference
+        // (critic_manager.cpp:70-73): redo this iteration with Obstacles only so that
+        // costs and u match it exactly
+        fail_flag = true;
+        fail_sticky = true;
+        const uint32_t only = (c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN)) |
+          (it > 0 ? SD_ACCUMULATE : 0u);
+        rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple);
+        if (rc != SMPC_OK) return rc;
+        rc = launch_combine(c, c->d_tuple, 1, furthest_cached ? c->d_furthest : nullptr);
+        if (rc != SMPC_OK) return rc;
+        HIPCK(c, hipEventRecord(c->ev1, c->stream));
+        fetched = false;
+      }
+    }
+  }
+  if (!fetched) {
+    rc = fetch_out(c);
+    if (rc != SMPC_OK) return rc;
+  }
+  const uint32_t furthest_seen = static_cast<uint32_t>(c->h_out[3 * T + 4]);
+  memcpy(u_inout, c->h_out, 3 * T * sizeof(float));
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    out->fail_flag = fail_flag ? 1 : 0;
+    out->furthest_valid = (need_f && furthest_cached) ? 1 : 0;
+    out->furthest_reached_path_point = out->furthest_valid ? furthest_seen : 0;
+    out->non_colliding = static_cast<uint32_t>(c->h_out[3 * T + 3]);
+    out->min_cost = c->h_out[3 * T + 0];
+    out->sum_w = c->h_out[3 * T + 1];
+    out->passes = c->passes;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->device_ms = ms;
+    out->score_pass_ms = profile_pass_ms(c);
+  }
+  return SMPC_OK;
+}
+
+int smpc_get_trajectories(smpc_ctx* c, float* x, float* y, float* yaws)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (!(c->cfg.flags & SMPC_FLAG_STORE_TRAJECTORIES))
+    return fail(c, SMPC_ERR_STATE, "ctx was created without SMPC_FLAG_STORE_TRAJECTORIES");
+  HIPCK(c, hipSetDevice(c->device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
+  if (x) HIPCK(c, hipMemcpy(x, c->d_traj[0], n, hipMemcpyDeviceToHost));
+  if (y) HIPCK(c, hipMemcpy(y, c->d_traj[1], n, hipMemcpyDeviceToHost));
+  if (yaws) HIPCK(c, hipMemcpy(yaws, c->d_traj[2], n, hipMemcpyDeviceToHost));
+  return SMPC_OK;
+}
+
+int smpc_get_costs(smpc_ctx* c, float* costs)
+{
+  if (!c || !costs) return SMPC_ERR_INVALID;
+  HIPCK(c, hipSetDevice(c->device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipMemcpy(costs, c->d_costs[c->costs_cur], c->cfg.batch_size * sizeof(float),
+                     hipMemcpyDeviceToHost));
+  return SMPC_OK;
+}
+
+// ---- batch-sharded path -------------------------------------------------------
+
+int smpc_set_stream(smpc_ctx* c, void* hip_stream)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return SMPC_OK;
+}
+
+uint32_t smpc_tuple_len(const smpc_ctx* c)
+{
+  return c ? SMPC_TUPLE_HEADER + 3 * c->cfg.time_steps : 0;
+}
+
+int smpc_shard_begin(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
+{
+  if (!c || !in || !u_in) return fail(c, SMPC_ERR_INVALID, "null argument");
+  HIPCK(c, hipSetDevice(c->device));
+  c->passes = 0;
+  c->evp_used = 0;
+  c->costs_cur = 0;
+  return prepare_tick(c, in, u_in);
+}
+
+int smpc_shard_furthest(smpc_ctx* c, float* d_furthest)
+{
+  if (!c || !d_furthest) return fail(c, SMPC_ERR_INVALID, "null argument");
+  if (!c->tick_ready) return fail(c, SMPC_ERR_STATE, "smpc_shard_begin first");
+  HIPCK(c, hipSetDevice(c->device));
+  return launch_furthest(c, d_furthest);
+}
+
+int smpc_shard_score(smpc_ctx* c, const float* d_furthest, uint32_t furthest_hint, float* d_tuple)
+{
+  if (!c || !d_tuple) return fail(c, SMPC_ERR_INVALID, "null argument");
+  if (!c->tick_ready) return fail(c, SMPC_ERR_STATE, "smpc_shard_begin first");
+  HIPCK(c, hipSetDevice(c->device));
+  // fail_flag is batch-wide: a shard never short-circuits on its own rollouts
+  return launch_score(c, scoring_flags(c, c->fail_in), nullptr, d_furthest, furthest_hint, d_tuple);
+}
+
+int smpc_shard_rescore_failed(smpc_ctx* c, float* d_tuple)
+{
+  if (!c || !d_tuple) return fail(c, SMPC_ERR_INVALID, "null argument");
+  if (!c->tick_ready) return fail(c, SMPC_ERR_STATE, "smpc_shard_begin first");
+  HIPCK(c, hipSetDevice(c->device));
+  const uint32_t only = c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN);
+  return launch_score(c, only, nullptr, nullptr, 0, d_tuple);
+}
+
+int smpc_shard_combine(smpc_ctx* c, const float* d_tuples, uint32_t n_tuples, float* u_out,
+                       smpc_tick_out* out)
+{
+  if (!c || !d_tuples || n_tuples == 0 || !u_out) return fail(c, SMPC_ERR_INVALID, "null argument");
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = launch_combine(c, d_tuples, n_tuples, nullptr);
+  if (rc != SMPC_OK) return rc;
+  rc = fetch_out(c);
+  if (rc != SMPC_OK) return rc;
+  const uint32_t T = c->cfg.time_steps;
+  memcpy(u_out, c->h_out, 3 * T * sizeof(float));
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    const bool obstacles_scored = (scoring_flags(c, c->fail_in) & SD_OBSTACLES) != 0;
+    out->fail_flag = (c->fail_in || (obstacles_scored && c->h_out[3 * T + 3] == 0.0f)) ? 1 : 0;
+    out->furthest_valid = (c->gate_flags & SD_NEED_FURTHEST) ? 1 : 0;
+    out->furthest_reached_path_point = static_cast<uint32_t>(c->h_out[3 * T + 2]);
+    out->non_colliding = static_cast<uint32_t>(c->h_out[3 * T + 3]);
+    out->min_cost = c->h_out[3 * T + 0];
+    out->sum_w = c->h_out[3 * T + 1];
+    out->passes = c->passes;
+    out->score_pass_ms = profile_pass_ms(c);
+  }
+  return SMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// smpc_dev.h — host<->kernel parameter block and launch geometry (internal).
+#ifndef SMPC_DEV_H_
+#define SMPC_DEV_H_
+
+#include <stdint.h>
+
+// critic / mode bits of SmpcDev::flags
+#define SD_OBSTACLES 0x001u       // ObstaclesCritic scored this pass
+#define SD_PATH_ALIGN 0x002u      // PathAlignCritic past its host-side gates (still gated per S)
+#define SD_PATH_FOLLOW 0x004u     // PathFollowCritic past its gates
+#define SD_GOAL_ANGLE 0x008u      // GoalAngleCritic (robot within threshold of the goal)
+#define SD_PREFER_FORWARD 0x010u  // PreferForwardCritic past its gate
+#define SD_USE_PATH_YAW 0x020u    // PathAlign use_path_orientations
+#define SD_ACCUMULATE 0x040u      // costs start from costs_prev (iteration > 0)
+#define SD_STORE_TRAJ 0x080u      // write x,y,yaw [B,T]
+#define SD_TRACK_UNKNOWN 0x100u   // costmap tracks unknown space (255 is not a collision)
+#define SD_NEED_FURTHEST 0x200u   // some critic consumes furthest_reached_path_point
+
+#define SMPC_MAX_PATH 1024        // path points staged in LDS
+#define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
+
+struct SmpcLut {  // per 8-bit cost: {margin - d | 0, R_infl - d | 0}  (obstacles_critic.cpp:159-170)
+  float crit;
+  float rep;
+};
+
+struct SmpcDev {
+  // sizes
+  uint32_t B, T, P;
+  uint32_t nsamp;  // PathAlign samples per trajectory: (T-1)/step
+  uint32_t step;   // trajectory_point_step
+  uint32_t flags;
+  // robot state (Optimizer::prepare)
+  double x0, y0;
+  float yaw0, cos0, sin0;
+  float svx, svy, swz;
+  float dt;
+  // tensors
+  const float* nvx;
+  const float* nvy;
+  const float* nwz;
+  const float* u;           // [3T] control sequence (device)
+  const float* costs_prev;  // [B] (SD_ACCUMULATE)
+  float* costs;             // [B]
+  float* traj_x;            // [B,T] (SD_STORE_TRAJ)
+  float* traj_y;
+  float* traj_yaw;
+  // costmap
+  const uint8_t* map;
+  uint32_t W, H;
+  double ox, oy, res;
+  int32_t win_x0, win_y0, win_w, win_h;  // window staged in LDS (cells)
+  const SmpcLut* lut;                     // [256]
+  // path block (device)
+  const float* px;
+  const float* py;
+  const float* pyaw;
+  const float* D;            // cumulative path length, P-1 entries (path_align_critic.cpp:83-90)
+  const uint8_t* pvalid;     // P-1 entries
+  const uint8_t* pa_active;  // [P] PathAlign gate per candidate furthest point
+  const uint32_t* pf_idx;    // [P] PathFollow target index per candidate furthest point
+  // furthest point: device value (float) if non-null, else the hint
+  const float* d_furthest;
+  uint32_t furthest_hint;
+  // critic constants
+  float obs_critical_w, obs_repulsion_w, obs_collision_cost;
+  uint32_t obs_power;
+  float pa_weight;
+  uint32_t pa_power;
+  float pf_weight;
+  uint32_t pf_power;
+  float ga_weight, ga_goal_yaw;
+  uint32_t ga_power;
+  float pfw_weight;
+  uint32_t pfw_power;
+  float g_vx, g_vy, g_wz;  // gamma / std^2 (optimizer.cpp:367-379)
+  float neg_inv_temp;      // -1 / temperature (optimizer.cpp:383)
+  // outputs
+  float* partials;         // [gridDim.x][4 + 3T] per-block softmax partials
+  uint32_t* furthest_out;  // atomicMax target of the furthest-only pass (float bits)
+};
+
+// LDS carve-up, computed once on the host and passed to the kernel.
+struct SmpcLds {
+  uint32_t off_lut, off_px, off_py, off_pyaw, off_D, off_valid, off_scr;
+  uint32_t scr_stride;  // floats per wave of scratch
+  uint32_t total;       // bytes
+};
+
+#endif

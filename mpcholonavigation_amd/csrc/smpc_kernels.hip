@@ -1,0 +1,791 @@
+// smpc_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the sampling-MPC hot path.
+//
+// One wavefront (64 lanes) owns one rollout at a time; lane l holds time steps
+// [l*R, l*R+R) of the horizon in registers (R = ceil(T/64)).  The reference's
+// [B,T] tensor passes (noise add, predict, integrate, critics, softmax update;
+// reference src/optimizer.cpp:157-164,227-233,313-343,362-394) collapse into
+// one streaming pass over the three noise tensors:
+//
+//   noise row (coalesced 256 B/array) -> c = u + n -> v = shift(c) ->
+//   yaw = scan(wz dt) -> sincos -> x,y = scan(...) -> critics (costmap window
+//   and path in LDS) -> cost -> online softmax accumulation of w*c per wave ->
+//   per-block partial {min, sum w, sum w*c[3T]}.
+//
+// Cross-lane work uses DPP row shifts / broadcasts (no LDS traffic); there is
+// no dense contraction anywhere, hence no MFMA: the bound is HBM (12*T bytes of
+// noise per rollout) against FP32 VALU for the two transcendentals per step.
+//
+// Compiled with -ffp-contract=off so that a*b+c keeps the two roundings of the
+// reference's separate xtensor passes.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smpc_dev.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------
+// cross-lane helpers (DPP; gfx9 row_shr / row_bcast / wave_shr)
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL,
+                                                    ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// inclusive + scan over the 64 lanes (all lanes must be active)
+__device__ __forceinline__ float wave_scan_add(float v)
+{
+  v += dpp_f<0x111>(0.f, v);        // row_shr:1
+  v += dpp_f<0x112>(0.f, v);        // row_shr:2
+  v += dpp_f<0x114>(0.f, v);        // row_shr:4
+  v += dpp_f<0x118>(0.f, v);        // row_shr:8
+  v += dpp_f<0x142, 0xA>(0.f, v);   // row_bcast:15 -> rows 1,3
+  v += dpp_f<0x143, 0xC>(0.f, v);   // row_bcast:31 -> rows 2,3
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+  v = wave_scan_add(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+  const float inf = __int_as_float(0x7f800000);
+  v = fminf(v, dpp_f<0x111>(inf, v));
+  v = fminf(v, dpp_f<0x112>(inf, v));
+  v = fminf(v, dpp_f<0x114>(inf, v));
+  v = fminf(v, dpp_f<0x118>(inf, v));
+  v = fminf(v, dpp_f<0x142, 0xA>(inf, v));
+  v = fminf(v, dpp_f<0x143, 0xC>(inf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v)
+{
+  v = min(v, dpp_u<0x111>(0xffffffffu, v));
+  v = min(v, dpp_u<0x112>(0xffffffffu, v));
+  v = min(v, dpp_u<0x114>(0xffffffffu, v));
+  v = min(v, dpp_u<0x118>(0xffffffffu, v));
+  v = min(v, dpp_u<0x142, 0xA>(0xffffffffu, v));
+  v = min(v, dpp_u<0x143, 0xC>(0xffffffffu, v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// value of lane-1 (lane 0 gets `first`)
+__device__ __forceinline__ float wave_shr1(float v, float first)
+{
+  return dpp_f<0x138>(first, v);  // wave_shr:1
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// std::pow(double, unsigned) for the cost_power parameters (H5: pow promotes to double)
+__device__ __forceinline__ double powu(double v, uint32_t p)
+{
+  if (p == 1u) return v;
+  double r = 1.0;
+  while (p) {
+    if (p & 1u) r *= v;
+    v *= v;
+    p >>= 1;
+  }
+  return r;
+}
+// data.costs += xt::pow(v, power)
+__device__ __forceinline__ float add_cost_pow(float c, double v, uint32_t power)
+{
+  return (float)((double)c + powu(v, power));
+}
+
+// utils::normalize_angles (tools/utils.hpp:258-263), double like the reference
+__device__ __forceinline__ double normalize_angle(double a)
+{
+  const double theta = fmod(a + M_PI, 2.0 * M_PI);
+  return theta <= 0.0 ? theta + M_PI : theta - M_PI;
+}
+
+// Costmap2D::worldToMap + getCost through the LDS window (global fallback).
+// Off-map -> NO_INFORMATION (obstacles_critic.cpp:209-212).
+__device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const uint8_t* s_map, float x,
+                                            float y)
+{
+  const double wx = (double)x, wy = (double)y;
+  if (wx < p.ox || wy < p.oy) return 255u;
+  const double qx = (wx - p.ox) / p.res;
+  const double qy = (wy - p.oy) / p.res;
+  if (!(qx < 4294967296.0) || !(qy < 4294967296.0)) return 255u;
+  const uint32_t mx = (uint32_t)qx, my = (uint32_t)qy;
+  if (mx >= p.W || my >= p.H) return 255u;
+  const int lx = (int)mx - p.win_x0, ly = (int)my - p.win_y0;
+  if ((uint32_t)lx < (uint32_t)p.win_w && (uint32_t)ly < (uint32_t)p.win_h)
+    return s_map[ly * p.win_w + lx];
+  return p.map[(size_t)my * p.W + mx];
+}
+
+// ---------------------------------------------------------------------------
+// The streaming pass.  FURTHEST_ONLY = 1: rollout + endpoint argmin only
+// (utils::findPathFurthestReachedPoint, tools/utils.hpp:292-319).
+// ---------------------------------------------------------------------------
+template <int R, int FURTHEST_ONLY>
+__global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds L)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint8_t* s_map = smem;
+  const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
+  float* s_px = reinterpret_cast<float*>(smem + L.off_px);
+  float* s_py = reinterpret_cast<float*>(smem + L.off_py);
+  float* s_pyaw = reinterpret_cast<float*>(smem + L.off_pyaw);
+  float* s_D = reinterpret_cast<float*>(smem + L.off_D);
+  uint8_t* s_valid = smem + L.off_valid;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int wave = tid >> 6;
+  const int nwave = blockDim.x >> 6;
+  float* scr = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
+  float* scr_x = scr;
+  float* scr_y = scr + p.T;
+  float* scr_yaw = scr + 2 * p.T;
+
+  // ---- stage costmap window, LUT and path into LDS -------------------------
+  if (!FURTHEST_ONLY && (p.flags & SD_OBSTACLES)) {
+    const int ww = p.win_w, wh = p.win_h;
+    const bool vec = ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
+    if (vec) {
+      const int w4 = ww >> 2;
+      for (int i = tid; i < w4 * wh; i += blockDim.x) {
+        const int ry = i / w4, rx = i - ry * w4;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(
+          p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0);
+        reinterpret_cast<uint32_t*>(s_map)[ry * w4 + rx] = src[rx];
+      }
+    } else {
+      for (int i = tid; i < ww * wh; i += blockDim.x) {
+        const int ry = i / ww, rx = i - ry * ww;
+        s_map[i] = p.map[(size_t)(p.win_y0 + ry) * p.W + p.win_x0 + rx];
+      }
+    }
+    for (int i = tid; i < 256; i += blockDim.x)
+      const_cast<SmpcLut*>(s_lut)[i] = p.lut[i];
+  }
+  for (uint32_t i = tid; i < p.P; i += blockDim.x) {
+    s_px[i] = p.px[i];
+    s_py[i] = p.py[i];
+    if (!FURTHEST_ONLY) {
+      s_pyaw[i] = p.pyaw[i];
+      if (i + 1 < p.P) {
+        s_D[i] = p.D[i];
+        s_valid[i] = p.pvalid[i];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per-lane constants --------------------------------------------------
+  const uint32_t T = p.T;
+  const int t0 = lane * R;
+  float uvx[R], uvy[R], uwz[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool a = (uint32_t)(t0 + r) < T;
+    uvx[r] = a ? p.u[t0 + r] : 0.f;
+    uvy[r] = a ? p.u[T + t0 + r] : 0.f;
+    uwz[r] = a ? p.u[2 * T + t0 + r] : 0.f;
+  }
+  const float dt = p.dt;
+
+  uint32_t S = 0;       // batch-wide furthest point used for scoring
+  bool pa_on = false;
+  float pf_x = 0.f, pf_y = 0.f;
+  if (!FURTHEST_ONLY) {
+    if (p.flags & SD_NEED_FURTHEST) {
+      S = p.d_furthest ? (uint32_t)(*p.d_furthest) : p.furthest_hint;
+      if (S >= p.P) S = p.P ? p.P - 1 : 0;
+    }
+    pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && p.pa_active[S] && S > 0;
+    if ((p.flags & SD_PATH_FOLLOW) && p.P > 0) {
+      const uint32_t idx = p.pf_idx[S];
+      pf_x = s_px[idx];
+      pf_y = s_py[idx];
+    }
+  }
+
+  // running softmax state of this wave (optimizer.cpp:382-391 as an online sum)
+  float m_run = 3.0e38f, s_run = 0.f;
+  float Ux[R], Uy[R], Uz[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) Ux[r] = Uy[r] = Uz[r] = 0.f;
+  uint32_t S_local = 0, n_noncoll = 0;
+
+  const uint32_t gw = blockIdx.x * nwave + wave;
+  const uint32_t nW = gridDim.x * nwave;
+
+  for (uint32_t b = gw; b < p.B; b += nW) {
+    // ---- NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74) -----
+    const size_t row = (size_t)b * T;
+    float cvx[R], cvy[R], cwz[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool a = (uint32_t)(t0 + r) < T;
+      const float n0 = a ? p.nvx[row + t0 + r] : 0.f;
+      const float n1 = a ? p.nvy[row + t0 + r] : 0.f;
+      const float n2 = a ? p.nwz[row + t0 + r] : 0.f;
+      cvx[r] = uvx[r] + n0;
+      cvy[r] = uvy[r] + n1;
+      cwz[r] = uwz[r] + n2;
+    }
+    // ---- updateStateVelocities + predict: v[:,0]=speed, v[:,1:]=c[:,:-1] ---
+    float vx[R], vy[R], wz[R];
+    vx[0] = wave_shr1(cvx[R - 1], p.svx);
+    vy[0] = wave_shr1(cvy[R - 1], p.svy);
+    wz[0] = wave_shr1(cwz[R - 1], p.swz);
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      vx[r] = cvx[r - 1];
+      vy[r] = cvy[r - 1];
+      wz[r] = cwz[r - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((uint32_t)(t0 + r) >= T) vx[r] = vy[r] = wz[r] = 0.f;
+    }
+    // ---- integrateStateVelocities (optimizer.cpp:313-343) -------------------
+    float yaw[R];
+    {
+      float acc = wz[0] * dt;
+      yaw[0] = acc;
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        acc += wz[r] * dt;
+        yaw[r] = acc;
+      }
+      const float incl = wave_scan_add(acc);
+      const float excl = wave_shr1(incl, 0.f);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        yaw[r] = (lane == 0 ? yaw[r] : excl + yaw[r]) + p.yaw0;
+      }
+    }
+    float x[R], y[R];
+    {
+      float sn[R], cs[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) sincosf(yaw[r], &sn[r], &cs[r]);
+      // cos_[t] = cos(yaw[t-1]), cos_[0] = cosf(initial_yaw)
+      float c_prev = wave_shr1(cs[R - 1], p.cos0);
+      float s_prev = wave_shr1(sn[R - 1], p.sin0);
+      float ax = 0.f, ay = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float dxr = vx[r] * c_prev - vy[r] * s_prev;
+        const float dyr = vx[r] * s_prev + vy[r] * c_prev;
+        ax = (r == 0) ? dxr * dt : ax + dxr * dt;
+        ay = (r == 0) ? dyr * dt : ay + dyr * dt;
+        x[r] = ax;
+        y[r] = ay;
+        c_prev = cs[r];
+        s_prev = sn[r];
+      }
+      const float ex = wave_shr1(wave_scan_add(ax), 0.f);
+      const float ey = wave_shr1(wave_scan_add(ay), 0.f);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float cx = lane == 0 ? x[r] : ex + x[r];
+        const float cy = lane == 0 ? y[r] : ey + y[r];
+        x[r] = (float)(p.x0 + (double)cx);
+        y[r] = (float)(p.y0 + (double)cy);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((uint32_t)(t0 + r) < T) {
+        scr_x[t0 + r] = x[r];
+        scr_y[t0 + r] = y[r];
+        if (!FURTHEST_ONLY && (p.flags & SD_USE_PATH_YAW)) scr_yaw[t0 + r] = yaw[r];
+      }
+    }
+    if (!FURTHEST_ONLY && (p.flags & SD_STORE_TRAJ)) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if ((uint32_t)(t0 + r) < T) {
+          p.traj_x[row + t0 + r] = x[r];
+          p.traj_y[row + t0 + r] = y[r];
+          p.traj_yaw[row + t0 + r] = yaw[r];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- nearest path point of the endpoint (utils.hpp:292-319) -----------
+    uint32_t a_b = 0;
+    if (FURTHEST_ONLY || (p.flags & SD_NEED_FURTHEST)) {
+      const float ex = scr_x[T - 1], ey = scr_y[T - 1];
+      float best = 3.4028234663852886e38f;  // numeric_limits<float>::max()
+      uint32_t bi = 0xffffffffu;
+      for (uint32_t j = lane; j < p.P; j += WAVE) {
+        const float ddx = s_px[j] - ex, ddy = s_py[j] - ey;
+        const float d = ddx * ddx + ddy * ddy;
+        if (d < best) {
+          best = d;
+          bi = j;
+        }
+      }
+      const float gbest = wave_min(best);
+      // first index attaining the minimum; none (all >= FLT_MAX / NaN) -> 0
+      a_b = wave_min_u((best == gbest && bi != 0xffffffffu) ? bi : 0xffffffffu);
+      if (a_b == 0xffffffffu) a_b = 0;
+      S_local = max(S_local, a_b);
+    }
+    if (FURTHEST_ONLY) continue;
+
+    float cost = (p.flags & SD_ACCUMULATE) ? p.costs_prev[b] : 0.f;
+
+    // ---- ObstaclesCritic (obstacles_critic.cpp:114-178) ---------------------
+    if (p.flags & SD_OBSTACLES) {
+      float crit = 0.f, rep = 0.f;
+      int first_r = R;  // first colliding step inside this lane
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if ((uint32_t)(t0 + r) < T && first_r == R) {
+          const uint32_t c = cost_at(p, s_map, x[r], y[r]);
+          const bool collide = (c == 254u) || (c == 253u) ||
+            (c == 255u && !(p.flags & SD_TRACK_UNKNOWN));
+          if (collide) {
+            first_r = r;
+          } else {
+            const SmpcLut e = s_lut[c];
+            crit += e.crit;
+            rep += e.rep;
+          }
+        }
+      }
+      const unsigned long long cm = __ballot(first_r < R);
+      const bool collided = cm != 0ull;
+      if (collided) {
+        const int lc = __ffsll((long long)cm) - 1;
+        if (lane > lc) rep = 0.f;  // steps after the first collision are never visited
+      } else {
+        n_noncoll++;
+      }
+      const float rep_sum = wave_sum(rep);
+      const float raw = collided ? p.obs_collision_cost : wave_sum(crit);
+      const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
+      cost = add_cost_pow(cost, (double)v, p.obs_power);
+    }
+
+    // ---- PathAlignCritic (path_align_critic.cpp:92-135) ----------------------
+    if (pa_on) {
+      const uint32_t K = p.nsamp;
+      const bool smp = (uint32_t)lane < K;
+      float Tx = 0.f, Ty = 0.f, chord = 0.f;
+      if (smp) {
+        const uint32_t q = (lane + 1) * p.step;
+        Tx = scr_x[q];
+        Ty = scr_y[q];
+        const float ddx = Tx - scr_x[q - p.step], ddy = Ty - scr_y[q - p.step];
+        chord = sqrtf(ddx * ddx + ddy * ddy);
+      }
+      const float dist = wave_scan_add(chord);
+      // lower_bound over D[0..S)
+      uint32_t lo = 0, hi = S;
+      while (__any(lo < hi)) {
+        if (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_D[mid] < dist) lo = mid + 1; else hi = mid;
+        }
+      }
+      uint32_t cand;
+      if (lo >= S) {
+        cand = S - 1;  // reference dereferences end(): defined as size-1
+      } else if (lo == 0) {
+        cand = 0;
+      } else {
+        cand = (dist - s_D[lo - 1] < s_D[lo] - dist) ? lo - 1 : lo;
+      }
+      // findClosestPathPt's `iter == begin + init -> return 0` chains through path_pt
+      uint32_t pt = 0, prev = 0;
+      for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t Lk = (uint32_t)__builtin_amdgcn_readlane((int)lo, k);
+        const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cand, k);
+        const uint32_t cur = (Lk == prev) ? 0u : ck;
+        if ((uint32_t)lane == k) pt = cur;
+        prev = cur;
+      }
+      const bool ok = smp && s_valid[pt];
+      float d = 0.f;
+      if (ok) {
+        const float ddx = s_px[pt] - Tx, ddy = s_py[pt] - Ty;
+        if (p.flags & SD_USE_PATH_YAW) {
+          const double dd = (double)scr_yaw[(lane + 1) * p.step] - (double)s_pyaw[pt];
+          double a = fmod(fmod(dd, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+          if (a > M_PI) a -= 2.0 * M_PI;
+          const float dyaw = (float)a;
+          d = sqrtf(ddx * ddx + ddy * ddy + dyaw * dyaw);
+        } else {
+          d = sqrtf(ddx * ddx + ddy * ddy);
+        }
+      }
+      const float summed = wave_sum(d);
+      const float num = (float)__popcll(__ballot(ok));
+      const float c_pa = num > 0.f ? summed / num : 0.f;
+      cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
+    }
+
+    // ---- PathFollowCritic (path_follow_critic.cpp:56-70) ---------------------
+    if (p.flags & SD_PATH_FOLLOW) {
+      const double ddx = (double)(scr_x[T - 1] - pf_x);
+      const double ddy = (double)(scr_y[T - 1] - pf_y);
+      const double dist = sqrt(ddx * ddx + ddy * ddy);
+      cost = add_cost_pow(cost, (double)p.pf_weight * dist, p.pf_power);
+    }
+
+    // ---- GoalAngleCritic (goal_angle_critic.cpp:36-50) -----------------------
+    if (p.flags & SD_GOAL_ANGLE) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if ((uint32_t)(t0 + r) < T) s += fabs(normalize_angle((double)(p.ga_goal_yaw - yaw[r])));
+      }
+      const double mean = wave_sum_d(s) / (double)T;
+      cost = add_cost_pow(cost, mean * (double)p.ga_weight, p.ga_power);
+    }
+
+    // ---- PreferForwardCritic (prefer_forward_critic.cpp:33-47) ---------------
+    if (p.flags & SD_PREFER_FORWARD) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) s += fmaxf(-vx[r], 0.f) * dt;
+      cost = add_cost_pow(cost, (double)(wave_sum(s) * p.pfw_weight), p.pfw_power);
+    }
+
+    // ---- updateControlSequence gamma terms (optimizer.cpp:365-380) -----------
+    {
+      float gx = 0.f, gz = 0.f, gy = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        gx += uvx[r] * (cvx[r] - uvx[r]);
+        gz += uwz[r] * (cwz[r] - uwz[r]);
+        gy += uvy[r] * (cvy[r] - uvy[r]);
+      }
+      cost += p.g_vx * wave_sum(gx);
+      cost += p.g_wz * wave_sum(gz);
+      cost += p.g_vy * wave_sum(gy);
+    }
+    if (lane == 0) p.costs[b] = cost;
+
+    // ---- online softmax accumulation -----------------------------------------
+    const float m_new = fminf(m_run, cost);
+    const float f = expf(p.neg_inv_temp * (m_run - m_new));   // rescale old sums (<= 1)
+    const float w = expf(p.neg_inv_temp * (cost - m_new));
+    s_run = s_run * f + w;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      Ux[r] = Ux[r] * f + w * cvx[r];
+      Uy[r] = Uy[r] * f + w * cvy[r];
+      Uz[r] = Uz[r] * f + w * cwz[r];
+    }
+    m_run = m_new;
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- block combine -> one partial per block --------------------------------
+  __syncthreads();
+  if (FURTHEST_ONLY) {
+    // S_local >= 0 as float bits is order preserving
+    uint32_t* s_red = reinterpret_cast<uint32_t*>(smem + L.off_scr);
+    if (lane == 0) s_red[wave] = S_local;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t m = 0;
+      for (int w = 0; w < nwave; ++w) m = max(m, s_red[w]);
+      atomicMax(p.furthest_out, __float_as_uint((float)m));
+    }
+    return;
+  }
+  const uint32_t TL = 4 + 3 * T;  // == scr_stride is guaranteed >= TL by the host
+  float* myp = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
+  if (lane == 0) {
+    myp[0] = m_run;
+    myp[1] = s_run;
+    myp[2] = (float)S_local;
+    myp[3] = (float)n_noncoll;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if ((uint32_t)(t0 + r) < T) {
+      myp[4 + t0 + r] = Ux[r];
+      myp[4 + T + t0 + r] = Uy[r];
+      myp[4 + 2 * T + t0 + r] = Uz[r];
+    }
+  }
+  __syncthreads();
+  const float* allp = reinterpret_cast<const float*>(smem + L.off_scr);
+  float bm = 3.0e38f;
+  for (int w = 0; w < nwave; ++w) bm = fminf(bm, allp[(size_t)w * L.scr_stride]);
+  float* outp = p.partials + (size_t)blockIdx.x * TL;
+  for (uint32_t i = tid; i < TL; i += blockDim.x) {
+    float acc = 0.f;
+    if (i == 0) {
+      acc = bm;
+    } else if (i == 2) {
+      for (int w = 0; w < nwave; ++w) acc = fmaxf(acc, allp[(size_t)w * L.scr_stride + 2]);
+    } else if (i == 3) {
+      for (int w = 0; w < nwave; ++w) acc += allp[(size_t)w * L.scr_stride + 3];
+    } else {
+      for (int w = 0; w < nwave; ++w) {
+        const float mw = allp[(size_t)w * L.scr_stride];
+        const float sc = expf(p.neg_inv_temp * (mw - bm));
+        acc += sc * allp[(size_t)w * L.scr_stride + i];
+      }
+    }
+    outp[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Reduce the per-block partials of one pass into one shard tuple
+// {min, sum w, furthest, non-colliding, U[3T]}.  One block.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __restrict__ partials,
+                                                            uint32_t nblk, uint32_t T,
+                                                            float neg_inv_temp,
+                                                            float* __restrict__ tuple)
+{
+  __shared__ float s_red[16];
+  __shared__ float s_red2[16];
+  __shared__ float s_red3[16];
+  const uint32_t TL = 4 + 3 * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  float m = 3.0e38f, fu = 0.f, nc = 0.f;
+  for (uint32_t g = tid; g < nblk; g += blockDim.x) {
+    m = fminf(m, partials[(size_t)g * TL]);
+    fu = fmaxf(fu, partials[(size_t)g * TL + 2]);
+    nc += partials[(size_t)g * TL + 3];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fminf(m, __shfl_xor(m, o, WAVE));
+    fu = fmaxf(fu, __shfl_xor(fu, o, WAVE));
+    nc += __shfl_xor(nc, o, WAVE);
+  }
+  if (lane == 0) {
+    s_red[wave] = m;
+    s_red2[wave] = fu;
+    s_red3[wave] = nc;
+  }
+  __syncthreads();
+  m = 3.0e38f;
+  fu = 0.f;
+  nc = 0.f;
+  for (int w = 0; w < nwave; ++w) {
+    m = fminf(m, s_red[w]);
+    fu = fmaxf(fu, s_red2[w]);
+    nc += s_red3[w];
+  }
+  // per-block rescale factors exp(-(m_g - m)/temperature), once
+  __shared__ float s_sc[2048];
+  for (uint32_t g = tid; g < nblk; g += blockDim.x)
+    s_sc[g] = expf(neg_inv_temp * (partials[(size_t)g * TL] - m));
+  __syncthreads();
+  // columns 1 (sum w) and 4.. (U): thread (c, slice); slices split the blocks
+  const uint32_t ncol = TL;
+  const uint32_t slices = blockDim.x / 256 ? blockDim.x / 256 : 1;  // 4 slices of 256 columns
+  __shared__ float s_acc[4][256];
+  for (uint32_t c0 = 0; c0 < ncol; c0 += 256) {
+    const uint32_t c = c0 + (tid & 255);
+    const uint32_t sl = tid >> 8;
+    float acc = 0.f;
+    if (c < ncol && c != 0 && c != 2 && c != 3) {
+#pragma unroll 8
+      for (uint32_t g = sl; g < nblk; g += slices) {
+        acc += s_sc[g] * partials[(size_t)g * TL + c];
+      }
+    }
+    s_acc[sl][tid & 255] = acc;
+    __syncthreads();
+    if (sl == 0 && c < ncol) {
+      float r = 0.f;
+      for (uint32_t s = 0; s < slices; ++s) r += s_acc[s][tid & 255];
+      if (c == 0) r = m;
+      if (c == 2) r = fu;
+      if (c == 3) r = nc;
+      tuple[c] = r;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Combine G shard tuples into the new control sequence (optimizer.cpp:382-393):
+// rescale by exp(-(min_g - min)/temperature), divide by sum w, clip.
+// result: {min, sum_w, furthest, non_colliding}.  One block.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restrict__ tuples,
+                                                          uint32_t G, uint32_t T,
+                                                          float neg_inv_temp, float vx_max,
+                                                          float vx_min, float vy_max,
+                                                          float wz_max, float* __restrict__ u_out,
+                                                          float* __restrict__ result,
+                                                          const float* __restrict__ furthest_used)
+{
+  const uint32_t TL = 4 + 3 * T;
+  float m = 3.0e38f, fu = 0.f, nc = 0.f;
+  for (uint32_t g = 0; g < G; ++g) {
+    m = fminf(m, tuples[(size_t)g * TL]);
+    fu = fmaxf(fu, tuples[(size_t)g * TL + 2]);
+    nc += tuples[(size_t)g * TL + 3];
+  }
+  float sw = 0.f;
+  for (uint32_t g = 0; g < G; ++g)
+    sw += expf(neg_inv_temp * (tuples[(size_t)g * TL] - m)) * tuples[(size_t)g * TL + 1];
+  for (uint32_t i = threadIdx.x; i < 3 * T; i += blockDim.x) {
+    float acc = 0.f;
+    for (uint32_t g = 0; g < G; ++g)
+      acc += expf(neg_inv_temp * (tuples[(size_t)g * TL] - m)) * tuples[(size_t)g * TL + 4 + i];
+    float v = acc / sw;
+    // applyControlSequenceConstraints (optimizer.cpp:237-249)
+    if (i < T) v = fminf(fmaxf(v, vx_min), vx_max);
+    else if (i < 2 * T) v = fminf(fmaxf(v, -vy_max), vy_max);
+    else v = fminf(fmaxf(v, -wz_max), wz_max);
+    u_out[i] = v;
+  }
+  if (threadIdx.x == 0) {
+    result[0] = m;
+    result[1] = sw;
+    result[2] = fu;
+    result[3] = nc;
+    // the furthest point the critics consumed (cached across iterations)
+    result[4] = furthest_used ? *furthest_used : fu;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Device RNG: Philox4x32-10 + Box–Muller, one block of two samples per thread
+// (stands in for xt::random::randn, noise_generator.cpp:107-122).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t& o0,
+                                              uint32_t& o1)
+{
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    if (r > 0) {
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = lo1;
+    c2 = n2;
+    c3 = lo0;
+  }
+  o0 = c0;
+  o1 = c1;
+}
+
+__global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, uint64_t n,
+                                                      uint64_t base, uint64_t seed,
+                                                      uint32_t stream, uint32_t epoch,
+                                                      float sigma)
+{
+  // thread q handles global elements 2q, 2q+1 of the pair grid covering [base, base+n)
+  const uint64_t q_first = base >> 1;
+  const uint64_t q_last = (base + n + 1) >> 1;  // exclusive
+  for (uint64_t q = q_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_last;
+       q += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t r0, r1;
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, epoch, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r0, r1);
+    const float u1 = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float radius = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.2831853071795864769f * u2;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    const uint64_t e0 = q << 1, e1 = e0 + 1;
+    if (e0 >= base && e0 < base + n) out[e0 - base] = radius * cs * sigma;
+    if (e1 >= base && e1 < base + n) out[e1 - base] = radius * sn * sigma;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (called from smpc_api.cpp through plain C++ linkage)
+// ---------------------------------------------------------------------------
+template <int FO>
+static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint32_t grid,
+                                uint32_t block, hipStream_t st)
+{
+  switch (R) {
+    case 1: hipLaunchKernelGGL((smpc_pass<1, FO>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 2: hipLaunchKernelGGL((smpc_pass<2, FO>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 4: hipLaunchKernelGGL((smpc_pass<4, FO>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t smpc_launch_pass(int R, bool furthest_only, const SmpcDev& p, const SmpcLds& L,
+                            uint32_t grid, uint32_t block, hipStream_t st)
+{
+  return furthest_only ? launch_pass_r<1>(R, p, L, grid, block, st)
+                       : launch_pass_r<0>(R, p, L, grid, block, st);
+}
+
+hipError_t smpc_set_pass_lds_limit(int bytes)
+{
+  hipError_t e = hipSuccess;
+#define SET(R, FO)                                                                              \
+  if (e == hipSuccess)                                                                          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass<R, FO>),                   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  SET(1, 0) SET(2, 0) SET(4, 0) SET(1, 1) SET(2, 1) SET(4, 1)
+#undef SET
+  return e;
+}
+
+hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
+                              float neg_inv_temp, float* tuple, hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_reduce_partials, dim3(1), dim3(1024), 0, st, partials, nblk, T,
+                     neg_inv_temp, tuple);
+  return hipGetLastError();
+}
+
+hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, float neg_inv_temp,
+                               float vx_max, float vx_min, float vy_max, float wz_max,
+                               float* u_out, float* result, const float* furthest_used,
+                               hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_combine_tuples, dim3(1), dim3(256), 0, st, tuples, G, T, neg_inv_temp,
+                     vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used);
+  return hipGetLastError();
+}
+
+hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
+                                  uint32_t stream, uint32_t epoch, float sigma, hipStream_t st)
+{
+  const uint64_t pairs = (n + 3) / 2;
+  uint32_t grid = (uint32_t)((pairs + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid == 0) grid = 1;
+  hipLaunchKernelGGL(smpc_fill_noise, dim3(grid), dim3(256), 0, st, out, n, base, seed, stream,
+                     epoch, sigma);
+  return hipGetLastError();
+}

@@ -1,0 +1,162 @@
+"""Python face of libsmpc.so (include/smpc.h): the hot path of
+sortham::Optimizer::optimize() (reference src/optimizer.cpp:157-164) on MI355X.
+
+There is no fallback: if the HIP library is missing or no GPU is present, the
+constructor raises.  Names follow the reference: `optimize` is
+Optimizer::optimize, `get_generated_trajectories` is
+Optimizer::getGeneratedTrajectories, `reset` is Optimizer::reset's
+device half.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmpc.so")
+_lib = None
+
+
+class SmpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"smpc error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """dlopen libsmpc.so and bind every prototype of include/smpc.h.
+    Raises if the library was not built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C mpcholonavigation_amd/csrc` "
+                "(or __graft_entry__.build()); the sampling-MPC path has no CPU fallback")
+        _lib = A.bind(C.CDLL(LIB_PATH))
+        if _lib.smpc_abi_version() != A.SMPC_ABI_VERSION:
+            raise ImportError("libsmpc.so ABI version mismatch")
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Smpc:
+    """One optimizer context on one GPU (smpc_ctx)."""
+
+    def __init__(self, cfg: A.SmpcConfig):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.B, self.T = cfg.batch_size, cfg.time_steps
+        h = C.c_void_p()
+        rc = self.lib.smpc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise SmpcError(rc, self.lib.smpc_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.smpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise SmpcError(rc, self.lib.smpc_last_error(self.h).decode())
+
+    # ---- configuration ---------------------------------------------------
+    def reset(self):
+        self._ck(self.lib.smpc_reset(self.h))
+
+    def set_constraints(self, vx_max, vx_min, vy_max, wz_max):
+        self._ck(self.lib.smpc_set_constraints(self.h, vx_max, vx_min, vy_max, wz_max))
+
+    def set_critics(self, p: A.SmpcCriticParams):
+        self._ck(self.lib.smpc_set_critics(self.h, C.byref(p)))
+
+    def set_costmap(self, cells, origin_x, origin_y, resolution, track_unknown=False,
+                    inscribed_radius=0.1, cost_scaling_factor=10.0, inflation_radius=0.55):
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        if cells.ndim != 2:
+            raise ValueError("cells must be [height, width]")
+        h, w = cells.shape
+        self._ck(self.lib.smpc_set_costmap(
+            self.h, _ptr(cells), w, h, origin_x, origin_y, resolution, int(track_unknown),
+            inscribed_radius, cost_scaling_factor, inflation_radius))
+
+    def set_noise(self, nvx, nvy, nwz):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (nvx, nvy, nwz)]
+        for x in a:
+            if x.shape != (self.B, self.T):
+                raise ValueError(f"noise must be [{self.B}, {self.T}]")
+        self._ck(self.lib.smpc_set_noise(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2])))
+
+    def seed(self, seed):
+        self._ck(self.lib.smpc_seed(self.h, seed))
+
+    def get_noise(self):
+        out = [np.empty((self.B, self.T), np.float32) for _ in range(3)]
+        self._ck(self.lib.smpc_get_noise(self.h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
+        return out
+
+    # ---- hot path ----------------------------------------------------------
+    def optimize(self, tick, u):
+        """u: float32 [3, T] (vx, vy, wz) -> (u_new, SmpcTickOut)."""
+        u = np.ascontiguousarray(u, dtype=np.float32).copy()
+        if u.shape != (3, self.T):
+            raise ValueError(f"u must be [3, {self.T}]")
+        out = A.SmpcTickOut()
+        self._ck(self.lib.smpc_optimize(self.h, C.byref(tick.c), _ptr(u), C.byref(out)))
+        return u, out
+
+    def get_generated_trajectories(self):
+        out = [np.empty((self.B, self.T), np.float32) for _ in range(3)]
+        self._ck(self.lib.smpc_get_trajectories(self.h, _ptr(out[0]), _ptr(out[1]),
+                                                _ptr(out[2])))
+        return out
+
+    def get_costs(self):
+        c = np.empty(self.B, np.float32)
+        self._ck(self.lib.smpc_get_costs(self.h, _ptr(c)))
+        return c
+
+    # ---- batch-sharded phases (device pointers are plain ints) ------------------
+    def set_stream(self, hip_stream):
+        self._ck(self.lib.smpc_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    @property
+    def tuple_len(self):
+        return self.lib.smpc_tuple_len(self.h)
+
+    def shard_begin(self, tick, u):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        self._ck(self.lib.smpc_shard_begin(self.h, C.byref(tick.c), _ptr(u)))
+
+    def shard_furthest(self, d_furthest):
+        self._ck(self.lib.smpc_shard_furthest(self.h, C.c_void_p(d_furthest)))
+
+    def shard_score(self, d_furthest, furthest_hint, d_tuple):
+        self._ck(self.lib.smpc_shard_score(
+            self.h, C.c_void_p(d_furthest) if d_furthest else None, int(furthest_hint),
+            C.c_void_p(d_tuple)))
+
+    def shard_rescore_failed(self, d_tuple):
+        self._ck(self.lib.smpc_shard_rescore_failed(self.h, C.c_void_p(d_tuple)))
+
+    def shard_combine(self, d_tuples, n_tuples):
+        u = np.zeros((3, self.T), np.float32)
+        out = A.SmpcTickOut()
+        self._ck(self.lib.smpc_shard_combine(self.h, C.c_void_p(d_tuples), n_tuples, _ptr(u),
+                                             C.byref(out)))
+        return u, out

@@ -1,0 +1,108 @@
+"""Batch-sharded tick over torch.distributed.
+
+One process per GPU; rank g owns rows [g*B/G, (g+1)*B/G) of the rollout batch.
+The control sequence, path and costmap are replicated.  Per tick there are at
+most two exchanges, both tiny (latency-bound, not link-bound):
+
+  1. MAX over ranks of the local furthest reached path point (one float) —
+     PathAlign / PathFollow consume the batch-wide value
+     (reference tools/utils.hpp:292-319);
+  2. all-gather of the shard tuples {min cost, sum w, furthest, non-colliding,
+     sum w*c[3T]}; every rank then combines them with the softmax's shift
+     invariance (rescale by exp(-(min_g - min)/temperature)) — the reference's
+     updateControlSequence (src/optimizer.cpp:382-393) on the whole batch.
+
+With `speculate=True` exchange 1 is skipped: each rank scores with the furthest
+point of the previous tick; the all-gathered tuples carry the true value, and on
+a miss every rank re-scores with it (exact result either way).
+
+The driver is backend-agnostic: `HipShard` feeds libsmpc device pointers; the
+CPU tests plug in an oracle-backed backend with gloo.  torch is plumbing here
+(tensors for the collectives, streams); the arithmetic is in the library.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HipShard:
+    """Adapter: Smpc context <-> torch CUDA tensors (device pointers)."""
+
+    def __init__(self, smpc):
+        self.smpc = smpc
+        self.tuple_len = smpc.tuple_len
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        smpc.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def begin(self, tick, u):
+        self.smpc.shard_begin(tick, u)
+
+    def furthest(self, t_furthest):
+        self.smpc.shard_furthest(t_furthest.data_ptr())
+
+    def score(self, t_furthest, hint, t_tuple):
+        self.smpc.shard_score(t_furthest.data_ptr() if t_furthest is not None else 0, hint,
+                              t_tuple.data_ptr())
+
+    def rescore_failed(self, t_tuple):
+        self.smpc.shard_rescore_failed(t_tuple.data_ptr())
+
+    def combine(self, t_tuples, n):
+        return self.smpc.shard_combine(t_tuples.data_ptr(), n)
+
+
+class ShardedOptimizer:
+    """Optimizer::optimize() over a batch sharded across the ranks of `group`."""
+
+    def __init__(self, backend, group=None, speculate=False):
+        self.b = backend
+        self.group = group
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = backend.device
+        L = backend.tuple_len
+        self.t_furthest = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t_tuple = torch.zeros(L, dtype=torch.float32, device=dev)
+        self.t_all = torch.zeros(self.G * L, dtype=torch.float32, device=dev)
+        self.speculate = speculate
+        self.hint = None          # furthest point of the previous tick
+        self.rescored = 0         # speculation misses so far
+
+    def _gather(self):
+        if self.G == 1:
+            self.t_all.copy_(self.t_tuple)
+        else:
+            dist.all_gather_into_tensor(self.t_all, self.t_tuple, group=self.group)
+
+    def optimize(self, tick, u):
+        """One tick: returns (u_new [3,T], SmpcTickOut) — identical on every rank."""
+        b = self.b
+        b.begin(tick, u)
+        if self.speculate and self.hint is not None:
+            b.score(None, self.hint, self.t_tuple)
+            self._gather()
+            u_new, out = b.combine(self.t_all, self.G)
+            if out.furthest_valid and out.furthest_reached_path_point != self.hint:
+                # miss: the gathered tuples carry the true batch-wide furthest point
+                self.rescored += 1
+                self.hint = int(out.furthest_reached_path_point)
+                b.score(None, self.hint, self.t_tuple)
+                self._gather()
+                u_new, out = b.combine(self.t_all, self.G)
+        else:
+            b.furthest(self.t_furthest)
+            if self.G > 1:
+                dist.all_reduce(self.t_furthest, op=dist.ReduceOp.MAX, group=self.group)
+            b.score(self.t_furthest, 0, self.t_tuple)
+            self._gather()
+            u_new, out = b.combine(self.t_all, self.G)
+            if out.furthest_valid:
+                self.hint = int(out.furthest_reached_path_point)
+        if out.fail_flag and not tick.fail_flag_in:
+            # all rollouts of the WHOLE batch collide: the reference scored nothing
+            # past Obstacles (critic_manager.cpp:70-73)
+            b.rescore_failed(self.t_tuple)
+            self._gather()
+            u_new, out2 = b.combine(self.t_all, self.G)
+            out2.fail_flag = 1
+            out = out2
+        return u_new, out

@@ -1,0 +1,273 @@
+"""GPU parity: the HIP path (through the C-ABI, libsmpc.so) against the CPU oracle
+on identical noise, costmap, plan and control sequence.
+
+Tolerance: emitted Twist (and the whole control sequence) within 1e-4 relative
+of the oracle — BASELINE.json north_star.  Integer outputs (fail flag, furthest
+reached path point, non-colliding count) must match exactly.
+"""
+import numpy as np
+import pytest
+
+from mpcholonavigation_amd import _abi as A
+from mpcholonavigation_amd.synthetic import make_noise, make_scenario
+from mpcholonavigation_amd.tick import Tick, default_config, default_critics
+from tests.helpers import assert_parity, configure, cost_flips, make_case, rel_err, twist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Smpc():
+    from mpcholonavigation_amd.optimizer import Smpc as S
+    return S
+
+
+@pytest.fixture(scope="module")
+def Oracle():
+    from oracle.loader import Oracle as O, build
+    build()
+    return O
+
+
+def run_pair(Smpc, Oracle, cfg, scn, noise, critics=None, tick=None, u0=None, store=False,
+             track_unknown=False):
+    if store:
+        cfg.flags |= A.SMPC_FLAG_STORE_TRAJECTORIES
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, critics=critics, noise=noise, track_unknown=track_unknown)
+    tick = tick or scn.tick
+    u0 = scn.u0 if u0 is None else u0
+    ug, og = g.optimize(tick, u0)
+    uo, oo = o.optimize(tick, u0)
+    return g, o, (ug, og), (uo, oo)
+
+
+def test_rollout_trajectories_match(Smpc, Oracle):
+    """Rollout (a4-a6): x, y, yaw of every rollout against the oracle."""
+    cfg, scn, noise = make_case(1000, 30)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, store=True)
+    xg, yg, wg = g.get_generated_trajectories()
+    xo, yo, wo = o.get_trajectories()
+    # float scan order differs from the sequential cumsum by a few ulp
+    assert np.max(np.abs(xg - xo)) < 2e-6
+    assert np.max(np.abs(yg - yo)) < 2e-6
+    assert np.max(np.abs(wg - wo)) < 2e-6
+
+
+@pytest.mark.parametrize("B,T", [(1000, 30), (2000, 56), (4096, 64), (512, 100), (300, 128),
+                                 (256, 200), (1, 64), (7, 2), (65, 1)])
+def test_cruise_parity(Smpc, Oracle, B, T):
+    """All five critics live (cruise scenario), several batch/horizon shapes incl.
+    cfg1 (1000x30), the reference default horizon 56, ragged T and tiny batches."""
+    cfg, scn, noise = make_case(B, T)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    assert og.non_colliding == oo.non_colliding
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"cruise {B}x{T}")
+
+
+def test_cfg2_parity(Smpc, Oracle):
+    """BASELINE configs[1]: 65 536 rollouts x 64 steps, 200x200 costmap."""
+    cfg, scn, noise = make_case(65536, 64)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    cg, co = g.get_costs(), o.get_costs()
+    flips = cost_flips(cg, co)
+    assert flips <= 4, flips     # last-ulp cell flips, out of 4.2 M lookups
+    assert_parity(ug, og, uo, oo, cg, co, max_flips=4, label="cfg2")
+    # against the oracle with double accumulation the agreement is much tighter
+    o.set_accumulate_double(True)
+    ud, _ = o.optimize(scn.tick, scn.u0)
+    assert rel_err(ug, ud) < 2e-5
+
+
+def test_cfg3_shape_parity(Smpc, Oracle):
+    """configs[2] shape at a batch the oracle finishes quickly: T=128 on a
+    2000x2000 costmap (window in LDS, the rest from HBM/L2)."""
+    cfg, scn, noise = make_case(8192, 128, map_size=2000)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label="cfg3 shape")
+
+
+def test_near_goal_parity(Smpc, Oracle):
+    """Goal 0.4 m ahead: GoalAngle live, PathAlign/PathFollow/PreferForward gated off."""
+    cfg, scn, noise = make_case(1000, 30, near_goal=True)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    assert not oo.furthest_valid and not og.furthest_valid
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="near goal")
+
+
+def test_all_collide_sets_fail_flag(Smpc, Oracle):
+    """Every rollout collides -> fail_flag, later critics not scored (critic_manager.cpp:70-73)."""
+    cfg, scn, noise = make_case(512, 30, all_lethal=True)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    assert og.fail_flag == 1 and oo.fail_flag == 1
+    assert og.non_colliding == 0
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="all collide")
+    # the retry after fallback(): fail flag sticky, no critic is scored
+    t = scn.tick
+    t2 = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw, t.goal_x,
+              t.goal_y, fail_flag_in=True)
+    u0 = np.zeros_like(scn.u0)
+    ug2, og2 = g.optimize(t2, u0)
+    uo2, oo2 = o.optimize(t2, u0)
+    assert og2.fail_flag == 1 and oo2.fail_flag == 1
+    assert_parity(ug2, og2, uo2, oo2, g.get_costs(), o.get_costs(), label="sticky fail")
+
+
+def test_two_iterations_accumulate_costs(Smpc, Oracle):
+    """iteration_count=2: costs accumulate, furthest point cached."""
+    cfg, scn, noise = make_case(2000, 56)
+    cfg.iteration_count = 2
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    assert og.passes == 2
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="2 iterations")
+
+
+def test_track_unknown_and_off_map(Smpc, Oracle):
+    """255 cells + rollouts leaving the map: NO_INFORMATION collides unless tracking unknown."""
+    for track in (False, True):
+        cfg, scn, noise = make_case(1000, 64, map_size=60)   # 3 m map: rollouts leave it
+        scn.cells[:, 40:44] = 255
+        g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, track_unknown=track)
+        assert og.non_colliding == oo.non_colliding
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1,
+                      label=f"unknown track={track}")
+
+
+def test_blocked_path_gates(Smpc, Oracle):
+    """Invalid path points: PathFollow skips ahead, PathAlign's occupancy gate stands down."""
+    cfg, scn, noise = make_case(1000, 56)
+    P = len(scn.tick.path_x)
+    valid = np.ones(P - 1, np.uint8)
+    valid[20:40] = 0
+    t = scn.tick
+    tick = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw,
+                t.goal_x, t.goal_y, path_pts_valid=valid)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, tick=tick)
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="blocked path")
+    valid[:] = 1
+    valid[3:6] = 0      # a few invalid points: PathAlign stays on, samples skip them
+    tick = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw,
+                t.goal_x, t.goal_y, path_pts_valid=valid)
+    ug, og = g.optimize(tick, scn.u0)
+    uo, oo = o.optimize(tick, scn.u0)
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="few invalid")
+
+
+def test_non_default_critic_params(Smpc, Oracle):
+    """cost_power 2, use_path_orientations, other weights/steps; curved plan; moving robot."""
+    cfg, scn, noise = make_case(1500, 60)
+    cr = default_critics()
+    cr.obstacles.cost_power = 2
+    cr.path_align.cost_power = 2
+    cr.path_align.use_path_orientations = 1
+    cr.path_align.trajectory_point_step = 3
+    cr.path_align.offset_from_furthest = 10
+    cr.path_follow.cost_power = 2
+    cr.path_follow.offset_from_furthest = 3
+    cr.prefer_forward.cost_power = 3
+    cr.prefer_forward.cost_weight = 7.5
+    t = scn.tick
+    P = len(t.path_x)
+    s = np.arange(P, dtype=np.float32) * np.float32(0.05)
+    path_x = (t.pose_x + s * np.cos(0.3 * s)).astype(np.float32)
+    path_y = (t.pose_y + s * np.sin(0.3 * s)).astype(np.float32)
+    path_yaw = (0.3 * s).astype(np.float32)
+    tick = Tick(t.pose_x + 0.013, t.pose_y - 0.021, 0.2, (0.25, -0.05, 0.3), path_x, path_y,
+                path_yaw, float(path_x[-1]), float(path_y[-1]))
+    u0 = scn.u0.copy()
+    u0[0] = np.linspace(0.2, 0.4, cfg.time_steps)
+    u0[1] = 0.05
+    u0[2] = np.linspace(-0.2, 0.3, cfg.time_steps)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, critics=cr, tick=tick,
+                                        u0=u0)
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1, label="custom critics")
+
+
+def test_single_critics(Smpc, Oracle):
+    """Each critic alone (the others disabled) and none at all."""
+    names = ["obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward", None]
+    for only in names:
+        near = only == "goal_angle"
+        cfg, scn, noise = make_case(800, 56, near_goal=near)
+        cr = default_critics()
+        for n in names[:-1]:
+            getattr(cr, n).enabled = 1 if n == only else 0
+        g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, critics=cr)
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"only {only}")
+
+
+def test_constraints_clip(Smpc, Oracle):
+    """setSpeedLimit-scaled constraints clip the updated sequence (optimizer.cpp:237-249)."""
+    cfg, scn, noise = make_case(1000, 30)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+        obj.set_constraints(0.25, -0.1, 0.01, 0.005)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert ug[0].max() <= np.float32(0.25) and ug[1].max() <= np.float32(0.01)
+    assert np.abs(ug[2]).max() <= np.float32(0.005)
+    assert_parity(ug, og, uo, oo, label="clip")
+
+
+def test_closed_loop_ticks(Smpc, Oracle):
+    """Ten ticks with the sequence fed back (shifted) like evalControl does."""
+    cfg, scn, noise = make_case(2000, 56)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+    ug = uo = scn.u0
+    for k in range(10):
+        ug, og = g.optimize(scn.tick, ug)
+        uo, oo = o.optimize(scn.tick, uo)
+        assert_parity(ug, og, uo, oo, label=f"tick {k}", rtol=2e-4)
+        # shiftControlSequence (optimizer.cpp:206-225) on both, identically
+        ug = np.concatenate([ug[:, 1:], ug[:, -1:]], axis=1)
+        uo = np.concatenate([uo[:, 1:], uo[:, -1:]], axis=1)
+        uo = ug.copy()      # re-synchronise: parity of one tick, not error growth
+
+
+def test_device_rng_matches_cpu_twin(Smpc, Oracle):
+    """Philox4x32-10 + Box-Muller noise: integer stream identical, normals within 1e-6."""
+    cfg = default_config(batch_size=777, time_steps=33)
+    g, o = Smpc(cfg), Oracle(cfg)
+    g.seed(2024)
+    o.seed(2024)
+    for a, b in zip(g.get_noise(), o.get_noise()):
+        assert np.max(np.abs(a - b)) < 2e-6
+    nvx, nvy, nwz = g.get_noise()
+    assert abs(nvx.std() - 0.2) < 0.01 and abs(nvy.std() - 0.2) < 0.01
+    assert abs(nwz.std() - 0.4) < 0.02 and abs(nvx.mean()) < 0.01
+    first = nvx.copy()
+    g.reset()
+    o.reset()            # next draw epoch on both
+    assert np.max(np.abs(g.get_noise()[0] - o.get_noise()[0])) < 2e-6
+    assert np.max(np.abs(g.get_noise()[0] - first)) > 0.1
+
+
+def test_error_paths(Smpc):
+    """Error convention: negative status + message, no exception across the ABI."""
+    from mpcholonavigation_amd.optimizer import SmpcError
+    with pytest.raises(SmpcError) as e:
+        Smpc(default_config(batch_size=0))
+    assert e.value.code == A.SMPC_ERR_INVALID
+    with pytest.raises(SmpcError) as e:
+        Smpc(default_config(time_steps=257))
+    assert e.value.code == A.SMPC_ERR_UNSUPPORTED
+    cfg, scn, noise = make_case(64, 30)
+    g = Smpc(cfg)
+    with pytest.raises(SmpcError) as e:      # no noise yet
+        g.optimize(scn.tick, scn.u0)
+    assert e.value.code == A.SMPC_ERR_STATE
+    g.set_noise(*noise)
+    with pytest.raises(SmpcError) as e:      # no costmap yet
+        g.optimize(scn.tick, scn.u0)
+    assert e.value.code == A.SMPC_ERR_STATE
+    cr = default_critics()
+    cr.obstacles.consider_footprint = 1
+    with pytest.raises(SmpcError) as e:
+        g.set_critics(cr)
+    assert e.value.code == A.SMPC_ERR_UNSUPPORTED
+    with pytest.raises(SmpcError):           # trajectories were not requested
+        g.get_generated_trajectories()
