@@ -21,8 +21,9 @@
 #include "../../include/smpc.h"
 #include "smpc_dev.h"
 
-hipError_t smpc_launch_pass(int R, bool furthest_only, const SmpcDev& p, const SmpcLds& L,
+hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
                             uint32_t grid, uint32_t block, hipStream_t st);
+hipError_t smpc_pass_occupancy(int R, int mode, uint32_t block, uint32_t lds_bytes, int* blocks_per_cu);
 hipError_t smpc_set_pass_lds_limit(int bytes);
 hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
                               float neg_inv_temp, float* tuple, hipStream_t st);
@@ -115,10 +116,23 @@ struct smpc_ctx {
   // per-tick prepared state
   SmpcDev dev{};
   uint32_t gate_flags = 0;   // critics past their host-side gates this tick
+  int score_mode = 0;        // 0: every cost_power == 1 (one fused reduction), 2: general
+  uint32_t occ_blocks = 1, occ_lds = 0xffffffffu;
+  int occ_mode = -1;
+  static int score_mode_for(const smpc_critic_params& cr)
+  {
+    return (cr.obstacles.cost_power == 1 && cr.path_align.cost_power == 1 &&
+           cr.path_follow.cost_power == 1 && cr.goal_angle.cost_power == 1 &&
+           cr.prefer_forward.cost_power == 1) ? 0 : 2;
+  }
   bool tick_ready = false;
   bool fail_in = false;
   uint32_t P = 0;
   uint32_t passes = 0;
+  // speculation on furthest_reached_path_point: last tick's value
+  bool hint_valid = false;
+  uint32_t hint = 0;
+  uint64_t spec_misses = 0;
   std::string err;
 };
 
@@ -337,13 +351,19 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   const float svy = static_cast<float>(in->speed_vy);
   const float swz = static_cast<float>(in->speed_wz);
   const float dt = c->cfg.model_dt;
+  // trajectories(0,0): first rollout point, identical for every rollout because
+  // v[:,0] is the measured speed (optimizer.cpp:258-267,331-342)
+  const float dx0 = svx * cos0 - svy * sin0;
+  const float dy0 = svx * sin0 + svy * cos0;
+  const float x00 = static_cast<float>(in->pose_x + static_cast<double>(dx0 * dt));
+  const float y00 = static_cast<float>(in->pose_y + static_cast<double>(dy0 * dt));
+  uint32_t cost_t0 = SMPC_COST_NO_INFORMATION;   // costAtPose of that point (obstacles_critic.cpp:203-212)
+  if (c->map.set) {
+    unsigned mx, my;
+    if (world_to_map(c->map, x00, y00, mx, my))
+      cost_t0 = c->map.cells[static_cast<size_t>(my) * c->map.W + mx];
+  }
   if (gates & SD_PATH_ALIGN) {
-    // trajectories(0,0): first rollout point, identical for every rollout because
-    // v[:,0] is the measured speed (optimizer.cpp:258-267,331-342)
-    const float dx0 = svx * cos0 - svy * sin0;
-    const float dy0 = svx * sin0 + svy * cos0;
-    const float x00 = static_cast<float>(in->pose_x + static_cast<double>(dx0 * dt));
-    const float y00 = static_cast<float>(in->pose_y + static_cast<double>(dy0 * dt));
     // utils::findPathTrajectoryInitialPoint (tools/utils.hpp:327-344)
     size_t init = 0;
     float best = std::numeric_limits<float>::max();
@@ -416,6 +436,19 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.traj_x = c->d_traj[0]; d.traj_y = c->d_traj[1]; d.traj_yaw = c->d_traj[2];
   d.map = c->d_map; d.W = c->map.W; d.H = c->map.H;
   d.ox = c->map.ox; d.oy = c->map.oy; d.res = c->map.res;
+  d.cost_t0 = cost_t0;
+  {
+    // fast cell index: float quotient + guard band (see cost_at in smpc_kernels.hip)
+    const double rinv = 1.0 / c->map.res;
+    d.oxf = static_cast<float>(c->map.ox);
+    d.oyf = static_cast<float>(c->map.oy);
+    d.rinvf = static_cast<float>(rinv);
+    const double e_o = std::max(std::fabs(c->map.ox - static_cast<double>(d.oxf)),
+                                std::fabs(c->map.oy - static_cast<double>(d.oyf)));
+    const double qmax = static_cast<double>(std::max(c->map.W, c->map.H)) + 2.0;
+    const double eps = 2.0 * (e_o * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
+    d.cell_eps = static_cast<float>(std::min(eps, 0.5));
+  }
   d.lut = reinterpret_cast<const SmpcLut*>(c->d_tick + tl.lut);
   d.px = reinterpret_cast<const float*>(c->d_tick + tl.px);
   d.py = reinterpret_cast<const float*>(c->d_tick + tl.py);
@@ -427,6 +460,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.obs_critical_w = cr.obstacles.critical_weight;
   d.obs_repulsion_w = cr.obstacles.repulsion_weight;
   d.obs_collision_cost = cr.obstacles.collision_cost;
+  d.obs_rep_over_T = cr.obstacles.repulsion_weight / static_cast<float>(T);
   d.obs_power = cr.obstacles.cost_power;
   d.pa_weight = cr.path_align.cost_weight; d.pa_power = cr.path_align.cost_power;
   d.pf_weight = cr.path_follow.cost_weight; d.pf_power = cr.path_follow.cost_power;
@@ -437,6 +471,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.g_vy = c->cfg.gamma / powf(c->cfg.vy_std, 2);
   d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
   d.neg_inv_temp = -1 / c->cfg.temperature;
+  d.k2 = d.neg_inv_temp * 1.4426950408889634f;
   d.partials = c->d_partials;
   d.furthest_out = reinterpret_cast<uint32_t*>(c->d_furthest);
 
@@ -461,13 +496,21 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
 
   // persistent grid: as many blocks as stay resident, never more than the work
   const uint32_t waves_per_block = kBlock / 64;
-  uint32_t by_lds = std::max(1u, kLdsPerCu / std::max(c->lds.total, 1u));
-  uint32_t per_cu = std::min(by_lds, 32u / waves_per_block);
+  const int mode_now = c->score_mode_for(cr);
+  if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
+    int nb = 0;
+    if (smpc_pass_occupancy(c->R, mode_now, kBlock, c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
+    c->occ_blocks = static_cast<uint32_t>(nb);
+    c->occ_lds = c->lds.total;
+    c->occ_mode = mode_now;
+  }
+  uint32_t per_cu = std::min(c->occ_blocks, 32u / waves_per_block);
   uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
 
   c->gate_flags = gates;
+  c->score_mode = mode_now;
   c->fail_in = in->fail_flag_in != 0;
   c->P = P;
   c->tick_ready = true;
@@ -481,7 +524,7 @@ int launch_furthest(smpc_ctx* c, float* d_furthest)
   d.flags = c->gate_flags & SD_NEED_FURTHEST;
   d.furthest_out = reinterpret_cast<uint32_t*>(d_furthest);
   SmpcLds L = make_lds(0, c->P, d.T, kBlock / 64, false);
-  HIPCK(c, smpc_launch_pass(c->R, true, d, L, c->grid, kBlock, c->stream));
+  HIPCK(c, smpc_launch_pass(c->R, 1, d, L, c->grid, kBlock, c->stream));
   return SMPC_OK;
 }
 
@@ -498,7 +541,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   d.costs_prev = c->d_costs[c->costs_cur ^ 1];
   const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
   if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
-  HIPCK(c, smpc_launch_pass(c->R, false, d, c->lds, c->grid, kBlock, c->stream));
+  HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, kBlock, c->stream));
   if (prof) {
     HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
     c->evp_used += 2;
@@ -697,6 +740,7 @@ int smpc_reset(smpc_ctx* c)
   HIPCK(c, hipMemsetAsync(c->d_costs[0], 0, c->cfg.batch_size * sizeof(float), c->stream));
   HIPCK(c, hipMemsetAsync(c->d_costs[1], 0, c->cfg.batch_size * sizeof(float), c->stream));
   c->tick_ready = false;
+  c->hint_valid = false;
   if (c->rng_mode) {
     c->epoch++;
     return draw_noise(c);
@@ -793,68 +837,109 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
   int rc = prepare_tick(c, in, u_inout);
   if (rc != SMPC_OK) return rc;
   const uint32_t T = c->cfg.time_steps;
+  const uint32_t iS = 3 * T + 2, iNC = 3 * T + 3, iSused = 3 * T + 4;
   c->passes = 0;
   c->evp_used = 0;
   c->costs_cur = 0;
   bool fail_sticky = c->fail_in;
-  bool furthest_cached = false;
   bool fail_flag = fail_sticky;
   bool fetched = false;
-  const bool need_f = (c->gate_flags & SD_NEED_FURTHEST) != 0;
+  // furthest_reached_path_point of this tick: evaluated once, then cached
+  // (setPathFurthestPointIfNotSet, utils.hpp:350-355)
+  bool S_known = false, S_on_device = false;
+  uint32_t S_host = 0;
+  const bool speculate = !(c->cfg.flags & SMPC_FLAG_NO_SPECULATION);
   for (uint32_t it = 0; it < c->cfg.iteration_count; ++it) {
     uint32_t flags = scoring_flags(c, fail_sticky);
     if (it > 0) flags |= SD_ACCUMULATE;
     const float* u_dev = it == 0 ? nullptr : c->d_out;
     c->costs_cur = it & 1;
-    if ((flags & SD_NEED_FURTHEST) && !furthest_cached) {
-      // setPathFurthestPointIfNotSet: evaluated once per tick (utils.hpp:350-355, H3)
-      rc = launch_furthest(c, c->d_furthest);
-      if (rc != SMPC_OK) return rc;
-      furthest_cached = true;
+    const float* dF = nullptr;
+    uint32_t hintS = 0;
+    bool spec_try = false;
+    if (flags & SD_NEED_FURTHEST) {
+      if (S_known) {
+        hintS = S_host;
+      } else if (S_on_device) {
+        dF = c->d_furthest;
+      } else if (speculate && c->hint_valid) {
+        // score with the previous tick's furthest point; the pass reports the true
+        // one and a miss is re-scored below, so the result is exact either way
+        spec_try = true;
+        hintS = c->hint;
+        flags |= SD_LOCAL_FURTHEST;
+      } else {
+        rc = launch_furthest(c, c->d_furthest);
+        if (rc != SMPC_OK) return rc;
+        S_on_device = true;
+        dF = c->d_furthest;
+      }
     }
-    rc = launch_score(c, flags, u_dev, (flags & SD_NEED_FURTHEST) ? c->d_furthest : nullptr, 0,
-                      c->d_tuple);
+    rc = launch_score(c, flags, u_dev, dF, hintS, c->d_tuple);
     if (rc != SMPC_OK) return rc;
-    rc = launch_combine(c, c->d_tuple, 1, furthest_cached ? c->d_furthest : nullptr);
+    rc = launch_combine(c, c->d_tuple, 1, dF);
     if (rc != SMPC_OK) return rc;
     HIPCK(c, hipEventRecord(c->ev1, c->stream));
     fetched = false;
-    if (flags & SD_OBSTACLES) {
-      // fail_flag = all trajectories collide (obstacles_critic.cpp:177) decides what the
-      // remaining critics and iterations may do: one host round trip (it is also the
-      // final read-back when this is the last iteration)
+    const bool last = it + 1 == c->cfg.iteration_count;
+    if ((flags & SD_OBSTACLES) || spec_try || last) {
+      // one host round trip: it carries fail_flag (obstacles_critic.cpp:177), the true
+      // furthest point, and on the last iteration the result itself
       rc = fetch_out(c);
       if (rc != SMPC_OK) return rc;
       fetched = true;
-      if (c->h_out[3 * T + 3] == 0.0f) {
-        // the critics after Obstacles were not scored in the reference
-        // (critic_manager.cpp:70-73): redo this iteration with Obstacles only so that
-        // costs and u match it exactly
-        fail_flag = true;
-        fail_sticky = true;
-        const uint32_t only = (c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN)) |
-          (it > 0 ? SD_ACCUMULATE : 0u);
-        rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple);
+    }
+    if (fetched && dF) {
+      S_host = static_cast<uint32_t>(c->h_out[iSused]);
+      S_known = true;
+    }
+    if (spec_try) {
+      const uint32_t S_true = static_cast<uint32_t>(c->h_out[iS]);
+      S_host = S_true;
+      S_known = true;
+      if (S_true != hintS) {
+        c->spec_misses++;
+        flags &= ~SD_LOCAL_FURTHEST;
+        rc = launch_score(c, flags, u_dev, nullptr, S_host, c->d_tuple);
         if (rc != SMPC_OK) return rc;
-        rc = launch_combine(c, c->d_tuple, 1, furthest_cached ? c->d_furthest : nullptr);
+        rc = launch_combine(c, c->d_tuple, 1, nullptr);
         if (rc != SMPC_OK) return rc;
         HIPCK(c, hipEventRecord(c->ev1, c->stream));
-        fetched = false;
+        rc = fetch_out(c);
+        if (rc != SMPC_OK) return rc;
       }
+    }
+    if ((flags & SD_OBSTACLES) && c->h_out[iNC] == 0.0f) {
+      // every rollout collides: the critics after Obstacles were not scored in the
+      // reference (critic_manager.cpp:70-73); redo this iteration with Obstacles only
+      // so that costs and u match it exactly
+      fail_flag = true;
+      fail_sticky = true;
+      const uint32_t only = (c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN)) |
+        (it > 0 ? SD_ACCUMULATE : 0u);
+      rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple);
+      if (rc != SMPC_OK) return rc;
+      rc = launch_combine(c, c->d_tuple, 1, nullptr);
+      if (rc != SMPC_OK) return rc;
+      HIPCK(c, hipEventRecord(c->ev1, c->stream));
+      fetched = false;
     }
   }
   if (!fetched) {
     rc = fetch_out(c);
     if (rc != SMPC_OK) return rc;
   }
-  const uint32_t furthest_seen = static_cast<uint32_t>(c->h_out[3 * T + 4]);
+  if (S_known) {
+    c->hint = S_host;
+    c->hint_valid = true;
+  }
   memcpy(u_inout, c->h_out, 3 * T * sizeof(float));
   if (out) {
     memset(out, 0, sizeof(*out));
     out->fail_flag = fail_flag ? 1 : 0;
-    out->furthest_valid = (need_f && furthest_cached) ? 1 : 0;
-    out->furthest_reached_path_point = out->furthest_valid ? furthest_seen : 0;
-    out->non_colliding = static_cast<uint32_t>(c->h_out[3 * T + 3]);
+    out->furthest_valid = S_known ? 1 : 0;
+    out->furthest_reached_path_point = S_known ? S_host : 0;
+    out->non_colliding = static_cast<uint32_t>(c->h_out[iNC]);
     out->min_cost = c->h_out[3 * T + 0];
     out->sum_w = c->h_out[3 * T + 1];
     out->passes = c->passes;
@@ -927,7 +1012,9 @@ int smpc_shard_score(smpc_ctx* c, const float* d_furthest, uint32_t furthest_hin
   if (!c->tick_ready) return fail(c, SMPC_ERR_STATE, "smpc_shard_begin first");
   HIPCK(c, hipSetDevice(c->device));
   // fail_flag is batch-wide: a shard never short-circuits on its own rollouts
-  return launch_score(c, scoring_flags(c, c->fail_in), nullptr, d_furthest, furthest_hint, d_tuple);
+  uint32_t flags = scoring_flags(c, c->fail_in);
+  if (flags & SD_NEED_FURTHEST) flags |= SD_LOCAL_FURTHEST;  // the tuple carries the true local value
+  return launch_score(c, flags, nullptr, d_furthest, furthest_hint, d_tuple);
 }
 
 int smpc_shard_rescore_failed(smpc_ctx* c, float* d_tuple)

@@ -15,6 +15,7 @@
 #define SD_STORE_TRAJ 0x080u      // write x,y,yaw [B,T]
 #define SD_TRACK_UNKNOWN 0x100u   // costmap tracks unknown space (255 is not a collision)
 #define SD_NEED_FURTHEST 0x200u   // some critic consumes furthest_reached_path_point
+#define SD_LOCAL_FURTHEST 0x400u  // the scoring pass also reports its own furthest point (speculation)
 
 #define SMPC_MAX_PATH 1024        // path points staged in LDS
 #define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
@@ -49,6 +50,9 @@ struct SmpcDev {
   const uint8_t* map;
   uint32_t W, H;
   double ox, oy, res;
+  float oxf, oyf, rinvf;   // float images for the fast cell index
+  float cell_eps;          // bound on |float quotient - double quotient| (guard band)
+  uint32_t cost_t0;        // costmap cost under trajectory point 0 (same for every rollout)
   int32_t win_x0, win_y0, win_w, win_h;  // window staged in LDS (cells)
   const SmpcLut* lut;                     // [256]
   // path block (device)
@@ -64,6 +68,7 @@ struct SmpcDev {
   uint32_t furthest_hint;
   // critic constants
   float obs_critical_w, obs_repulsion_w, obs_collision_cost;
+  float obs_rep_over_T;    // repulsion_weight / T (MODE 0)
   uint32_t obs_power;
   float pa_weight;
   uint32_t pa_power;
@@ -75,6 +80,7 @@ struct SmpcDev {
   uint32_t pfw_power;
   float g_vx, g_vy, g_wz;  // gamma / std^2 (optimizer.cpp:367-379)
   float neg_inv_temp;      // -1 / temperature (optimizer.cpp:383)
+  float k2;                // neg_inv_temp * log2(e): weights as 2^(k2 (c - min))
   // outputs
   float* partials;         // [gridDim.x][4 + 3T] per-block softmax partials
   uint32_t* furthest_out;  // atomicMax target of the furthest-only pass (float bits)

@@ -93,6 +93,11 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// 1-ulp hardware sqrt / reciprocal (MODE 0: the terms they feed are continuous in
+// their inputs, so a last-bit difference moves a cost by ~1e-7 relative)
+__device__ __forceinline__ float fast_sqrt(float v) {return __builtin_amdgcn_sqrtf(v);}
+__device__ __forceinline__ float fast_rcp(float v) {return __builtin_amdgcn_rcpf(v);}
+
 // std::pow(double, unsigned) for the cost_power parameters (H5: pow promotes to double)
 __device__ __forceinline__ double powu(double v, uint32_t p)
 {
@@ -118,31 +123,90 @@ __device__ __forceinline__ double normalize_angle(double a)
   return theta <= 0.0 ? theta + M_PI : theta - M_PI;
 }
 
+// sin and cos of a rollout yaw.  Cody–Waite reduction by pi/2 in three float
+// pieces (each fma is exact or correctly rounded on the cancelled difference)
+// and the Cephes single-precision minimax polynomials on [-pi/4, pi/4];
+// <= ~1 ulp.  Huge arguments take the library path.
+__device__ __forceinline__ void smpc_sincos(float x, float& sn, float& cs)
+{
+  if (__builtin_expect(!(fabsf(x) < 65536.0f), 0)) {
+    sincosf(x, &sn, &cs);
+    return;
+  }
+  const float k = rintf(x * 0.6366197466850281f);
+  float r = fmaf(-k, 1.5707963705062866f, x);
+  r = fmaf(-k, -4.371138828673793e-08f, r);
+  r = fmaf(-k, -1.7151245100058819e-15f, r);
+  const float z = r * r;
+  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  const float s = fmaf(ps * z, r, r);
+  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  const float c = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));
+  const int q = (int)k;
+  const float a = (q & 1) ? c : s;
+  const float b = (q & 1) ? s : c;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
+// Costmap2D::worldToMap along one axis, exactly as nav2_costmap_2d does it:
+// reject w < origin, else (unsigned)((w - origin) / resolution) in double.
+__device__ __forceinline__ bool cell_index_exact(double w, double o, double res, uint32_t n,
+                                                 uint32_t& m)
+{
+  if (w < o) return false;
+  const double q = (w - o) / res;
+  if (!(q < 4294967296.0)) return false;  // the reference's cast would be UB: off-map
+  m = (uint32_t)q;
+  return m < n;
+}
+
 // Costmap2D::worldToMap + getCost through the LDS window (global fallback).
 // Off-map -> NO_INFORMATION (obstacles_critic.cpp:209-212).
+//
+// The cell index is first formed in float, q = (x - origin_f) * (1/res)_f, whose
+// distance to the double quotient the reference truncates is bounded by
+// p.cell_eps (host: origin rounding + 3 float roundings).  Only a lane whose q
+// lies within that bound of a cell edge can truncate differently; those lanes
+// (a fraction ~4*cell_eps) redo both axes in double with the true division, so
+// every lookup reads the cell the reference reads.
 __device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const uint8_t* s_map, float x,
                                             float y)
 {
-  const double wx = (double)x, wy = (double)y;
-  if (wx < p.ox || wy < p.oy) return 255u;
-  const double qx = (wx - p.ox) / p.res;
-  const double qy = (wy - p.oy) / p.res;
-  if (!(qx < 4294967296.0) || !(qy < 4294967296.0)) return 255u;
-  const uint32_t mx = (uint32_t)qx, my = (uint32_t)qy;
-  if (mx >= p.W || my >= p.H) return 255u;
-  const int lx = (int)mx - p.win_x0, ly = (int)my - p.win_y0;
-  if ((uint32_t)lx < (uint32_t)p.win_w && (uint32_t)ly < (uint32_t)p.win_h)
-    return s_map[ly * p.win_w + lx];
-  return p.map[(size_t)my * p.W + mx];
+  const float qx = (x - p.oxf) * p.rinvf, qy = (y - p.oyf) * p.rinvf;
+  const float fx = floorf(qx), fy = floorf(qy);
+  const float rx = qx - fx, ry = qy - fy;
+  const float lo = p.cell_eps, hi = 1.0f - p.cell_eps;
+  uint32_t mx = (uint32_t)(int)fx, my = (uint32_t)(int)fy;   // negative / huge -> >= W
+  bool on = mx < p.W && my < p.H;
+  if (__builtin_expect(!(rx >= lo && rx <= hi && ry >= lo && ry <= hi), 0)) {
+    on = cell_index_exact((double)x, p.ox, p.res, p.W, mx);
+    on = cell_index_exact((double)y, p.oy, p.res, p.H, my) && on;
+  }
+  if (!on) return 255u;
+  const uint32_t lx = mx - (uint32_t)p.win_x0, ly = my - (uint32_t)p.win_y0;
+  // two separate loads (never a select of an LDS and a global pointer)
+  const bool inw = lx < (uint32_t)p.win_w && ly < (uint32_t)p.win_h;
+  uint32_t c = s_map[inw ? ly * p.win_w + lx : 0u];
+  if (__builtin_expect(!inw, 0)) c = p.map[(size_t)my * p.W + mx];
+  return c;
 }
 
 // ---------------------------------------------------------------------------
-// The streaming pass.  FURTHEST_ONLY = 1: rollout + endpoint argmin only
-// (utils::findPathFurthestReachedPoint, tools/utils.hpp:292-319).
+// The streaming pass.
+//   MODE 0: score, every cost_power == 1 (the defaults): all per-step terms of
+//           the additive critics go through ONE wave reduction
+//   MODE 1: rollout + endpoint argmin only (utils::findPathFurthestReachedPoint,
+//           tools/utils.hpp:292-319)
+//   MODE 2: score, general cost_power (pow in double per critic)
 // ---------------------------------------------------------------------------
-template <int R, int FURTHEST_ONLY>
-__global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds L)
+template <int R, int MODE>
+__global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pass(const SmpcDev p, const SmpcLds L)
 {
+  constexpr bool FURTHEST_ONLY = MODE == 1;
+  constexpr bool GENERIC = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
@@ -207,10 +271,19 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
     uwz[r] = a ? p.u[2 * T + t0 + r] : 0.f;
   }
   const float dt = p.dt;
+  float gux[R], guy[R], guz[R];   // gamma/std^2 * u (optimizer.cpp:367-379), MODE 0
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    gux[r] = p.g_vx * uvx[r];
+    guy[r] = p.g_vy * uvy[r];
+    guz[r] = p.g_wz * uwz[r];
+  }
 
   uint32_t S = 0;       // batch-wide furthest point used for scoring
   bool pa_on = false;
   float pf_x = 0.f, pf_y = 0.f;
+  uint32_t bs_iters = 0;
+  float pa_inv_spacing = 0.f;   // (S-1) / D[S-1]: mean inverse spacing of the plan
   if (!FURTHEST_ONLY) {
     if (p.flags & SD_NEED_FURTHEST) {
       S = p.d_furthest ? (uint32_t)(*p.d_furthest) : p.furthest_hint;
@@ -222,7 +295,14 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       pf_x = s_px[idx];
       pf_y = s_py[idx];
     }
+    bs_iters = S > 1 ? 32u - (uint32_t)__builtin_clz(S - 1) : 0u;  // ceil(log2 S)
+    if (pa_on && S > 1 && s_D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / s_D[S - 1];
   }
+  const bool want_local_furthest =
+    FURTHEST_ONLY || ((p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST));
+  // PathAlign sample of this lane: trajectory points q and q - step
+  const uint32_t pa_q = ((uint32_t)lane + 1u) * p.step;
+  const bool pa_smp = (uint32_t)lane < p.nsamp;
 
   // running softmax state of this wave (optimizer.cpp:382-391 as an online sum)
   float m_run = 3.0e38f, s_run = 0.f;
@@ -234,19 +314,38 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
   const uint32_t gw = blockIdx.x * nwave + wave;
   const uint32_t nW = gridDim.x * nwave;
 
+  // noise rows are prefetched one rollout ahead
+  float n0[R], n1[R], n2[R];
+  if (gw < p.B) {
+    const size_t row = (size_t)gw * T;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool a = (uint32_t)(t0 + r) < T;
+      n0[r] = a ? p.nvx[row + t0 + r] : 0.f;
+      n1[r] = a ? p.nvy[row + t0 + r] : 0.f;
+      n2[r] = a ? p.nwz[row + t0 + r] : 0.f;
+    }
+  }
+
   for (uint32_t b = gw; b < p.B; b += nW) {
     // ---- NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74) -----
     const size_t row = (size_t)b * T;
     float cvx[R], cvy[R], cwz[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const bool a = (uint32_t)(t0 + r) < T;
-      const float n0 = a ? p.nvx[row + t0 + r] : 0.f;
-      const float n1 = a ? p.nvy[row + t0 + r] : 0.f;
-      const float n2 = a ? p.nwz[row + t0 + r] : 0.f;
-      cvx[r] = uvx[r] + n0;
-      cvy[r] = uvy[r] + n1;
-      cwz[r] = uwz[r] + n2;
+      cvx[r] = uvx[r] + n0[r];
+      cvy[r] = uvy[r] + n1[r];
+      cwz[r] = uwz[r] + n2[r];
+    }
+    if (b + nW < p.B) {
+      const size_t nrow = (size_t)(b + nW) * T;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool a = (uint32_t)(t0 + r) < T;
+        n0[r] = a ? p.nvx[nrow + t0 + r] : 0.f;
+        n1[r] = a ? p.nvy[nrow + t0 + r] : 0.f;
+        n2[r] = a ? p.nwz[nrow + t0 + r] : 0.f;
+      }
     }
     // ---- updateStateVelocities + predict: v[:,0]=speed, v[:,1:]=c[:,:-1] ---
     float vx[R], vy[R], wz[R];
@@ -273,18 +372,15 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
         acc += wz[r] * dt;
         yaw[r] = acc;
       }
-      const float incl = wave_scan_add(acc);
-      const float excl = wave_shr1(incl, 0.f);
+      const float excl = wave_shr1(wave_scan_add(acc), 0.f);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        yaw[r] = (lane == 0 ? yaw[r] : excl + yaw[r]) + p.yaw0;
-      }
+      for (int r = 0; r < R; ++r) yaw[r] = (excl + yaw[r]) + p.yaw0;
     }
     float x[R], y[R];
     {
       float sn[R], cs[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) sincosf(yaw[r], &sn[r], &cs[r]);
+      for (int r = 0; r < R; ++r) smpc_sincos(yaw[r], sn[r], cs[r]);
       // cos_[t] = cos(yaw[t-1]), cos_[0] = cosf(initial_yaw)
       float c_prev = wave_shr1(cs[R - 1], p.cos0);
       float s_prev = wave_shr1(sn[R - 1], p.sin0);
@@ -304,10 +400,8 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       const float ey = wave_shr1(wave_scan_add(ay), 0.f);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float cx = lane == 0 ? x[r] : ex + x[r];
-        const float cy = lane == 0 ? y[r] : ey + y[r];
-        x[r] = (float)(p.x0 + (double)cx);
-        y[r] = (float)(p.y0 + (double)cy);
+        x[r] = (float)(p.x0 + (double)(ex + x[r]));
+        y[r] = (float)(p.y0 + (double)(ey + y[r]));
       }
     }
 #pragma unroll
@@ -333,8 +427,7 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- nearest path point of the endpoint (utils.hpp:292-319) -----------
-    uint32_t a_b = 0;
-    if (FURTHEST_ONLY || (p.flags & SD_NEED_FURTHEST)) {
+    if (want_local_furthest) {
       const float ex = scr_x[T - 1], ey = scr_y[T - 1];
       float best = 3.4028234663852886e38f;  // numeric_limits<float>::max()
       uint32_t bi = 0xffffffffu;
@@ -348,13 +441,21 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       }
       const float gbest = wave_min(best);
       // first index attaining the minimum; none (all >= FLT_MAX / NaN) -> 0
-      a_b = wave_min_u((best == gbest && bi != 0xffffffffu) ? bi : 0xffffffffu);
-      if (a_b == 0xffffffffu) a_b = 0;
+      uint32_t a_b;
+      if (p.P <= WAVE) {
+        const unsigned long long hit = __ballot(best == gbest && bi != 0xffffffffu);
+        a_b = hit ? (uint32_t)(__ffsll((long long)hit) - 1) : 0u;   // index == lane
+      } else {
+        a_b = wave_min_u((best == gbest && bi != 0xffffffffu) ? bi : 0xffffffffu);
+        if (a_b == 0xffffffffu) a_b = 0;
+      }
       S_local = max(S_local, a_b);
     }
     if (FURTHEST_ONLY) continue;
 
     float cost = (p.flags & SD_ACCUMULATE) ? p.costs_prev[b] : 0.f;
+    float lin = 0.f;    // MODE 0: per-lane sum of every additive per-step term
+    float uni = 0.f;    // MODE 0: wave-uniform terms
 
     // ---- ObstaclesCritic (obstacles_critic.cpp:114-178) ---------------------
     if (p.flags & SD_OBSTACLES) {
@@ -363,9 +464,10 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if ((uint32_t)(t0 + r) < T && first_r == R) {
-          const uint32_t c = cost_at(p, s_map, x[r], y[r]);
-          const bool collide = (c == 254u) || (c == 253u) ||
-            (c == 255u && !(p.flags & SD_TRACK_UNKNOWN));
+          // point 0 is the same for every rollout (v[:,0] is the measured speed): its
+          // cell was looked up once on the host with the same arithmetic
+          const uint32_t c = (t0 + r == 0) ? p.cost_t0 : cost_at(p, s_map, x[r], y[r]);
+          const bool collide = (c >= 253u) && !(c == 255u && (p.flags & SD_TRACK_UNKNOWN));
           if (collide) {
             first_r = r;
           } else {
@@ -383,32 +485,55 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       } else {
         n_noncoll++;
       }
-      const float rep_sum = wave_sum(rep);
-      const float raw = collided ? p.obs_collision_cost : wave_sum(crit);
-      const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
-      cost = add_cost_pow(cost, (double)v, p.obs_power);
+      if (GENERIC) {
+        const float rep_sum = wave_sum(rep);
+        const float raw = collided ? p.obs_collision_cost : wave_sum(crit);
+        const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
+        cost = add_cost_pow(cost, (double)v, p.obs_power);
+      } else {
+        lin = (collided ? 0.f : p.obs_critical_w * crit) + p.obs_rep_over_T * rep;
+        uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+      }
     }
 
     // ---- PathAlignCritic (path_align_critic.cpp:92-135) ----------------------
     if (pa_on) {
-      const uint32_t K = p.nsamp;
-      const bool smp = (uint32_t)lane < K;
       float Tx = 0.f, Ty = 0.f, chord = 0.f;
-      if (smp) {
-        const uint32_t q = (lane + 1) * p.step;
-        Tx = scr_x[q];
-        Ty = scr_y[q];
-        const float ddx = Tx - scr_x[q - p.step], ddy = Ty - scr_y[q - p.step];
-        chord = sqrtf(ddx * ddx + ddy * ddy);
+      if (pa_smp) {
+        Tx = scr_x[pa_q];
+        Ty = scr_y[pa_q];
+        const float ddx = Tx - scr_x[pa_q - p.step], ddy = Ty - scr_y[pa_q - p.step];
+        chord = GENERIC ? sqrtf(ddx * ddx + ddy * ddy) : fast_sqrt(ddx * ddx + ddy * ddy);
       }
       const float dist = wave_scan_add(chord);
-      // lower_bound over D[0..S)
-      uint32_t lo = 0, hi = S;
-      while (__any(lo < hi)) {
-        if (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_D[mid] < dist) lo = mid + 1; else hi = mid;
+      // std::lower_bound over D[0..S).  Plans are close to uniformly spaced, so the
+      // index is guessed from the mean spacing and confirmed against D[g-1], D[g],
+      // D[g+1]; a wave with any unconfirmed lane runs the branch-free binary search.
+      uint32_t g = (uint32_t)(dist * pa_inv_spacing);
+      g = g < S ? g : S - 1;
+      const float da = g > 0 ? s_D[g - 1] : -3.0e38f;
+      const float db = s_D[g];
+      const float dc = g + 1 < S ? s_D[g + 1] : 3.0e38f;
+      uint32_t lo;
+      float dl, dh;   // D[lo-1], D[lo]
+      const bool at_g = da < dist && !(db < dist);
+      const bool at_g1 = db < dist && !(dc < dist);
+      if (at_g) {
+        lo = g; dl = da; dh = db;
+      } else {
+        lo = g + 1; dl = db; dh = dc;
+      }
+      if (__builtin_expect(__any(!(at_g || at_g1)), 0)) {
+        uint32_t base = 0, n = S;
+        for (uint32_t it = 0; it < bs_iters; ++it) {
+          const uint32_t half = n >> 1;
+          base = (s_D[base + half - 1 + (half == 0)] < dist && half) ? base + half : base;
+          n -= half;
         }
+        const float d_base = s_D[base];
+        lo = base + (d_base < dist ? 1u : 0u);
+        dl = lo > 0 ? s_D[lo - 1] : 0.f;
+        dh = lo < S ? s_D[lo] : 0.f;
       }
       uint32_t cand;
       if (lo >= S) {
@@ -416,35 +541,49 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       } else if (lo == 0) {
         cand = 0;
       } else {
-        cand = (dist - s_D[lo - 1] < s_D[lo] - dist) ? lo - 1 : lo;
+        cand = (dist - dl < dh - dist) ? lo - 1 : lo;
       }
-      // findClosestPathPt's `iter == begin + init -> return 0` chains through path_pt
-      uint32_t pt = 0, prev = 0;
-      for (uint32_t k = 0; k < K; ++k) {
-        const uint32_t Lk = (uint32_t)__builtin_amdgcn_readlane((int)lo, k);
-        const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cand, k);
-        const uint32_t cur = (Lk == prev) ? 0u : ck;
-        if ((uint32_t)lane == k) pt = cur;
-        prev = cur;
+      // findClosestPathPt's `iter == begin + init -> return 0` chains through path_pt:
+      // path_pt_k = 0 where lo_k == path_pt_{k-1}.  With E_k = (lo_k == cand_{k-1} != 0 ...)
+      // the chain F_k = E_k & ~F_{k-1} is "every other bit of each run of ones".
+      uint32_t cand_v = cand;
+      asm volatile("" : "+v"(cand_v));   // DPP sources must sit in a VGPR
+      const uint32_t cand_prev = dpp_u<0x138>(0u, cand_v);   // wave_shr:1
+      unsigned long long E = __ballot(pa_smp && lo == cand_prev && cand != 0u);
+      uint32_t pt = cand;
+      if (E) {
+        unsigned long long F = E & ~(E << 1);
+        unsigned long long M = E & (E << 1);
+        F |= (F << 2) & M;
+        M &= M << 2;
+        F |= (F << 4) & M;
+        M &= M << 4;
+        F |= (F << 8) & M;
+        M &= M << 8;
+        F |= (F << 16) & M;
+        M &= M << 16;
+        F |= (F << 32) & M;
+        if ((F >> lane) & 1ull) pt = 0;
       }
-      const bool ok = smp && s_valid[pt];
+      const bool ok = pa_smp && s_valid[pt];
       float d = 0.f;
       if (ok) {
         const float ddx = s_px[pt] - Tx, ddy = s_py[pt] - Ty;
         if (p.flags & SD_USE_PATH_YAW) {
-          const double dd = (double)scr_yaw[(lane + 1) * p.step] - (double)s_pyaw[pt];
+          const double dd = (double)scr_yaw[pa_q] - (double)s_pyaw[pt];
           double a = fmod(fmod(dd, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
           if (a > M_PI) a -= 2.0 * M_PI;
           const float dyaw = (float)a;
           d = sqrtf(ddx * ddx + ddy * ddy + dyaw * dyaw);
         } else {
-          d = sqrtf(ddx * ddx + ddy * ddy);
+          d = GENERIC ? sqrtf(ddx * ddx + ddy * ddy) : fast_sqrt(ddx * ddx + ddy * ddy);
         }
       }
       const float summed = wave_sum(d);
       const float num = (float)__popcll(__ballot(ok));
-      const float c_pa = num > 0.f ? summed / num : 0.f;
-      cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
+      const float c_pa = num > 0.f ? (GENERIC ? summed / num : summed * fast_rcp(num)) : 0.f;
+      if (GENERIC) cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
+      else uni += c_pa * p.pa_weight;
     }
 
     // ---- PathFollowCritic (path_follow_critic.cpp:56-70) ---------------------
@@ -452,7 +591,8 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       const double ddx = (double)(scr_x[T - 1] - pf_x);
       const double ddy = (double)(scr_y[T - 1] - pf_y);
       const double dist = sqrt(ddx * ddx + ddy * ddy);
-      cost = add_cost_pow(cost, (double)p.pf_weight * dist, p.pf_power);
+      if (GENERIC) cost = add_cost_pow(cost, (double)p.pf_weight * dist, p.pf_power);
+      else uni += (float)((double)p.pf_weight * dist);
     }
 
     // ---- GoalAngleCritic (goal_angle_critic.cpp:36-50) -----------------------
@@ -463,7 +603,8 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
         if ((uint32_t)(t0 + r) < T) s += fabs(normalize_angle((double)(p.ga_goal_yaw - yaw[r])));
       }
       const double mean = wave_sum_d(s) / (double)T;
-      cost = add_cost_pow(cost, mean * (double)p.ga_weight, p.ga_power);
+      if (GENERIC) cost = add_cost_pow(cost, mean * (double)p.ga_weight, p.ga_power);
+      else uni += (float)(mean * (double)p.ga_weight);
     }
 
     // ---- PreferForwardCritic (prefer_forward_critic.cpp:33-47) ---------------
@@ -471,11 +612,12 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < R; ++r) s += fmaxf(-vx[r], 0.f) * dt;
-      cost = add_cost_pow(cost, (double)(wave_sum(s) * p.pfw_weight), p.pfw_power);
+      if (GENERIC) cost = add_cost_pow(cost, (double)(wave_sum(s) * p.pfw_weight), p.pfw_power);
+      else lin += s * p.pfw_weight;
     }
 
     // ---- updateControlSequence gamma terms (optimizer.cpp:365-380) -----------
-    {
+    if (GENERIC) {
       float gx = 0.f, gz = 0.f, gy = 0.f;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -486,19 +628,28 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
       cost += p.g_vx * wave_sum(gx);
       cost += p.g_wz * wave_sum(gz);
       cost += p.g_vy * wave_sum(gy);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        lin = fmaf(gux[r], cvx[r] - uvx[r], lin);
+        lin = fmaf(guz[r], cwz[r] - uwz[r], lin);
+        lin = fmaf(guy[r], cvy[r] - uvy[r], lin);
+      }
+      cost += uni + wave_sum(lin);
     }
     if (lane == 0) p.costs[b] = cost;
 
     // ---- online softmax accumulation -----------------------------------------
     const float m_new = fminf(m_run, cost);
-    const float f = expf(p.neg_inv_temp * (m_run - m_new));   // rescale old sums (<= 1)
-    const float w = expf(p.neg_inv_temp * (cost - m_new));
-    s_run = s_run * f + w;
+    // exp(-(c - m)/temperature) as one v_exp_f32: 2^(k2 (c - m)), k2 = -log2(e)/temperature
+    const float f = __builtin_amdgcn_exp2f(p.k2 * (m_run - m_new));   // rescale old sums (<= 1)
+    const float w = __builtin_amdgcn_exp2f(p.k2 * (cost - m_new));
+    s_run = fmaf(s_run, f, w);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      Ux[r] = Ux[r] * f + w * cvx[r];
-      Uy[r] = Uy[r] * f + w * cvy[r];
-      Uz[r] = Uz[r] * f + w * cwz[r];
+      Ux[r] = fmaf(Ux[r], f, w * cvx[r]);
+      Uy[r] = fmaf(Uy[r], f, w * cvy[r]);
+      Uz[r] = fmaf(Uz[r], f, w * cwz[r]);
     }
     m_run = m_new;
     __builtin_amdgcn_wave_barrier();
@@ -560,16 +711,17 @@ __global__ void __launch_bounds__(512) smpc_pass(const SmpcDev p, const SmpcLds 
 
 // ---------------------------------------------------------------------------
 // Reduce the per-block partials of one pass into one shard tuple
-// {min, sum w, furthest, non-colliding, U[3T]}.  One block.
+// {min, sum w, furthest, non-colliding, U[3T]}.  Block j owns 32 tuple columns;
+// its 1024 threads are 32 columns x 32 row slices (coalesced 128-B row pieces).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __restrict__ partials,
                                                             uint32_t nblk, uint32_t T,
                                                             float neg_inv_temp,
                                                             float* __restrict__ tuple)
 {
-  __shared__ float s_red[16];
-  __shared__ float s_red2[16];
-  __shared__ float s_red3[16];
+  __shared__ float s_red[16], s_red2[16], s_red3[16];
+  __shared__ float s_sc[2048];
+  __shared__ float s_acc[32][33];
   const uint32_t TL = 4 + 3 * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   float m = 3.0e38f, fu = 0.f, nc = 0.f;
@@ -598,35 +750,26 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
     nc += s_red3[w];
   }
   // per-block rescale factors exp(-(m_g - m)/temperature), once
-  __shared__ float s_sc[2048];
   for (uint32_t g = tid; g < nblk; g += blockDim.x)
     s_sc[g] = expf(neg_inv_temp * (partials[(size_t)g * TL] - m));
   __syncthreads();
-  // columns 1 (sum w) and 4.. (U): thread (c, slice); slices split the blocks
-  const uint32_t ncol = TL;
-  const uint32_t slices = blockDim.x / 256 ? blockDim.x / 256 : 1;  // 4 slices of 256 columns
-  __shared__ float s_acc[4][256];
-  for (uint32_t c0 = 0; c0 < ncol; c0 += 256) {
-    const uint32_t c = c0 + (tid & 255);
-    const uint32_t sl = tid >> 8;
-    float acc = 0.f;
-    if (c < ncol && c != 0 && c != 2 && c != 3) {
-#pragma unroll 8
-      for (uint32_t g = sl; g < nblk; g += slices) {
-        acc += s_sc[g] * partials[(size_t)g * TL + c];
-      }
-    }
-    s_acc[sl][tid & 255] = acc;
-    __syncthreads();
-    if (sl == 0 && c < ncol) {
-      float r = 0.f;
-      for (uint32_t s = 0; s < slices; ++s) r += s_acc[s][tid & 255];
-      if (c == 0) r = m;
-      if (c == 2) r = fu;
-      if (c == 3) r = nc;
-      tuple[c] = r;
-    }
-    __syncthreads();
+  const uint32_t col = blockIdx.x * 32 + (tid & 31);
+  const uint32_t sl = tid >> 5;  // 32 slices
+  float acc = 0.f;
+  if (col < TL && col != 0 && col != 2 && col != 3) {
+#pragma unroll 4
+    for (uint32_t g = sl; g < nblk; g += 32) acc += s_sc[g] * partials[(size_t)g * TL + col];
+  }
+  s_acc[sl][tid & 31] = acc;
+  __syncthreads();
+  if (sl == 0 && col < TL) {
+    float r = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) r += s_acc[s][tid & 31];
+    if (col == 0) r = m;
+    if (col == 2) r = fu;
+    if (col == 3) r = nc;
+    tuple[col] = r;
   }
 }
 
@@ -728,24 +871,38 @@ __global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, 
 // ---------------------------------------------------------------------------
 // launch wrappers (called from smpc_api.cpp through plain C++ linkage)
 // ---------------------------------------------------------------------------
-template <int FO>
+template <int MODE>
 static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint32_t grid,
                                 uint32_t block, hipStream_t st)
 {
   switch (R) {
-    case 1: hipLaunchKernelGGL((smpc_pass<1, FO>), dim3(grid), dim3(block), L.total, st, p, L); break;
-    case 2: hipLaunchKernelGGL((smpc_pass<2, FO>), dim3(grid), dim3(block), L.total, st, p, L); break;
-    case 4: hipLaunchKernelGGL((smpc_pass<4, FO>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 1: hipLaunchKernelGGL((smpc_pass<1, MODE>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 2: hipLaunchKernelGGL((smpc_pass<2, MODE>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 4: hipLaunchKernelGGL((smpc_pass<4, MODE>), dim3(grid), dim3(block), L.total, st, p, L); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t smpc_launch_pass(int R, bool furthest_only, const SmpcDev& p, const SmpcLds& L,
+// mode: 0 score (all cost_power == 1), 1 furthest only, 2 score (general cost_power)
+hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
                             uint32_t grid, uint32_t block, hipStream_t st)
 {
-  return furthest_only ? launch_pass_r<1>(R, p, L, grid, block, st)
-                       : launch_pass_r<0>(R, p, L, grid, block, st);
+  switch (mode) {
+    case 0: return launch_pass_r<0>(R, p, L, grid, block, st);
+    case 1: return launch_pass_r<1>(R, p, L, grid, block, st);
+    default: return launch_pass_r<2>(R, p, L, grid, block, st);
+  }
+}
+
+hipError_t smpc_pass_occupancy(int R, int mode, uint32_t block, uint32_t lds_bytes, int* blocks_per_cu)
+{
+  const void* f = nullptr;
+#define PICK(RR, MM) if (R == RR && mode == MM) f = reinterpret_cast<const void*>(&smpc_pass<RR, MM>);
+  PICK(1, 0) PICK(2, 0) PICK(4, 0) PICK(1, 1) PICK(2, 1) PICK(4, 1) PICK(1, 2) PICK(2, 2) PICK(4, 2)
+#undef PICK
+  if (!f) return hipErrorInvalidValue;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, (int)block, lds_bytes);
 }
 
 hipError_t smpc_set_pass_lds_limit(int bytes)
@@ -755,7 +912,7 @@ hipError_t smpc_set_pass_lds_limit(int bytes)
   if (e == hipSuccess)                                                                          \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass<R, FO>),                   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  SET(1, 0) SET(2, 0) SET(4, 0) SET(1, 1) SET(2, 1) SET(4, 1)
+  SET(1, 0) SET(2, 0) SET(4, 0) SET(1, 1) SET(2, 1) SET(4, 1) SET(1, 2) SET(2, 2) SET(4, 2)
 #undef SET
   return e;
 }
@@ -763,8 +920,9 @@ hipError_t smpc_set_pass_lds_limit(int bytes)
 hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
                               float neg_inv_temp, float* tuple, hipStream_t st)
 {
-  hipLaunchKernelGGL(smpc_reduce_partials, dim3(1), dim3(1024), 0, st, partials, nblk, T,
-                     neg_inv_temp, tuple);
+  const uint32_t TL = 4 + 3 * T;
+  hipLaunchKernelGGL(smpc_reduce_partials, dim3((TL + 31) / 32), dim3(1024), 0, st, partials, nblk,
+                     T, neg_inv_temp, tuple);
   return hipGetLastError();
 }
 

@@ -271,3 +271,38 @@ def test_error_paths(Smpc):
     assert e.value.code == A.SMPC_ERR_UNSUPPORTED
     with pytest.raises(SmpcError):           # trajectories were not requested
         g.get_generated_trajectories()
+
+
+def test_speculation_miss_is_rescored(Smpc, Oracle):
+    """The furthest point of the previous tick is only a guess: when the plan changes
+    the pass reports the true value and the tick is re-scored (passes == 2), so the
+    result still equals the oracle's.  SMPC_FLAG_NO_SPECULATION gives the two-pass mode."""
+    cfg, scn, noise = make_case(2000, 56)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+    ug, og = g.optimize(scn.tick, scn.u0)          # first tick: exact pre-pass, no hint yet
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert og.passes == 1
+    assert_parity(ug, og, uo, oo, label="tick 0")
+    ug, og = g.optimize(scn.tick, scn.u0)          # same inputs: the hint is right
+    assert og.passes == 1
+    assert_parity(ug, og, uo, oo, label="tick 1 (hit)")
+    t = scn.tick
+    # a plan with twice the spacing: the nearest-point index of every endpoint halves
+    P = len(t.path_x)
+    px = (t.pose_x + 0.1 * np.arange(P)).astype(np.float32)
+    tick2 = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, px, t.path_y, t.path_yaw,
+                 float(px[-1]), t.goal_y)
+    ug, og = g.optimize(tick2, scn.u0)
+    uo, oo = o.optimize(tick2, scn.u0)
+    assert og.passes == 2                          # miss -> re-scored with the true value
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="tick 2 (miss)")
+    cfg2, _, _ = make_case(2000, 56)
+    cfg2.flags |= A.SMPC_FLAG_NO_SPECULATION
+    g2 = Smpc(cfg2)
+    configure(g2, scn, noise=noise)
+    for _ in range(2):
+        ug2, og2 = g2.optimize(tick2, scn.u0)
+        assert og2.passes == 1
+    assert_parity(ug2, og2, uo, oo, label="two-pass mode")

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Developer tool: time the scoring pass with subsets of critics enabled
+(which part of the fused kernel costs what).  Needs a GPU."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mpcholonavigation_amd import _abi as A
+from mpcholonavigation_amd.optimizer import Smpc
+from mpcholonavigation_amd.synthetic import make_scenario
+from mpcholonavigation_amd.tick import default_config, default_critics
+
+B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 262144, int(sys.argv[2]) if len(sys.argv) > 2 else 64
+MAP = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+names = ["obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward"]
+sets = {"none": [], "obstacles": ["obstacles"], "path_align": ["path_align"],
+        "path_follow": ["path_follow"], "prefer_forward": ["prefer_forward"],
+        "all": names}
+cfg = default_config(batch_size=B, time_steps=T, flags=A.SMPC_FLAG_PROFILE)
+scn = make_scenario(T, map_size=MAP)
+g = Smpc(cfg)
+g.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
+g.seed(1)
+for label, on in sets.items():
+    cr = default_critics()
+    for n in names:
+        getattr(cr, n).enabled = 1 if n in on else 0
+    g.set_critics(cr)
+    ts, ds = [], []
+    for k in range(25):
+        u, out = g.optimize(scn.tick, scn.u0)
+        if k >= 5:
+            ts.append(out.score_pass_ms); ds.append(out.device_ms)
+    print(f"{label:15s} pass {np.median(ts)*1e3:8.1f} us  device {np.median(ds)*1e3:8.1f} us  passes {out.passes}")
