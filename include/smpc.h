@@ -290,7 +290,10 @@ int smpc_get_costs(smpc_ctx* ctx, float* costs);
  * peer.  All device pointers must be on this ctx's device and all work is
  * enqueued on the stream given to smpc_set_stream(). */
 
-/* hipStream_t to enqueue on (NULL = the ctx's own stream). */
+/* hipStream_t to enqueue on.  NULL is HIP's default (null) stream — what
+ * torch.cuda.current_stream() is unless the caller changed it;
+ * SMPC_STREAM_OWN goes back to the ctx's own non-blocking stream. */
+#define SMPC_STREAM_OWN ((void*)(intptr_t)-1)
 int smpc_set_stream(smpc_ctx* ctx, void* hip_stream);
 
 #define SMPC_TUPLE_HEADER 4 /* floats before U: min, sum_w, furthest, non_colliding */

@@ -979,7 +979,7 @@ int smpc_get_costs(smpc_ctx* c, float* costs)
 int smpc_set_stream(smpc_ctx* c, void* hip_stream)
 {
   if (!c) return SMPC_ERR_INVALID;
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = hip_stream == SMPC_STREAM_OWN ? c->own_stream : static_cast<hipStream_t>(hip_stream);
   return SMPC_OK;
 }
 

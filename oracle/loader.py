@@ -37,6 +37,7 @@ _PROTOTYPES = {
     "smpc_oracle_shard_furthest": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p, _f32p]),
     "smpc_oracle_shard_score": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p, C.c_uint32,
                                           _f32p]),
+    "smpc_oracle_shard_rescore_failed": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p, _f32p]),
     "smpc_oracle_shard_combine": (C.c_int, [_ctx, _f32p, C.c_uint32, _f32p,
                                             C.POINTER(A.SmpcTickOut)]),
     "smpc_oracle_set_state_velocities": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
@@ -191,6 +192,12 @@ class Oracle:
         t = np.zeros(A.SMPC_TUPLE_HEADER + 3 * self.T, np.float32)
         self._ck(self.lib.smpc_oracle_shard_score(self.h, C.byref(tick.c), ptr(u), int(furthest),
                                                   ptr(t)))
+        return t
+
+    def shard_rescore_failed(self, tick, u):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        t = np.zeros(A.SMPC_TUPLE_HEADER + 3 * self.T, np.float32)
+        self._ck(self.lib.smpc_oracle_shard_rescore_failed(self.h, C.byref(tick.c), ptr(u), ptr(t)))
         return t
 
     def shard_combine(self, tuples):

@@ -1145,8 +1145,10 @@ int smpc_oracle_shard_furthest(smpc_oracle * o, const smpc_tick_in * in, const f
   return SMPC_OK;
 }
 
-int smpc_oracle_shard_score(smpc_oracle * o, const smpc_tick_in * in, const float * u_in,
-                            uint32_t furthest, float * tuple)
+// obstacles_only: the re-score after the whole batch was found to collide
+// (critic_manager.cpp:70-73: nothing past Obstacles was scored)
+static int shard_score_impl(smpc_oracle * o, const smpc_tick_in * in, const float * u_in,
+                            uint32_t furthest, bool obstacles_only, float * tuple)
 {
   int rc = check_ready(o, in);
   if (rc != SMPC_OK) {return rc;}
@@ -1165,10 +1167,12 @@ int smpc_oracle_shard_score(smpc_oracle * o, const smpc_tick_in * in, const floa
   if (!fail_in) {
     score_obstacles(o, tk);
     o->fail_flag = false;
-    score_path_align(o, tk);
-    score_path_follow(o, tk);
-    score_goal_angle(o, tk);
-    score_prefer_forward(o, tk);
+    if (!obstacles_only) {
+      score_path_align(o, tk);
+      score_path_follow(o, tk);
+      score_goal_angle(o, tk);
+      score_prefer_forward(o, tk);
+    }
   }
   add_gamma_terms(o, u_in);
   float cmin = std::numeric_limits<float>::max();
@@ -1197,6 +1201,18 @@ int smpc_oracle_shard_score(smpc_oracle * o, const smpc_tick_in * in, const floa
     tuple[SMPC_TUPLE_HEADER + 2 * T + t] = static_cast<float>(az[t]);
   }
   return SMPC_OK;
+}
+
+int smpc_oracle_shard_score(smpc_oracle * o, const smpc_tick_in * in, const float * u_in,
+                            uint32_t furthest, float * tuple)
+{
+  return shard_score_impl(o, in, u_in, furthest, false, tuple);
+}
+
+int smpc_oracle_shard_rescore_failed(smpc_oracle * o, const smpc_tick_in * in,
+                                     const float * u_in, float * tuple)
+{
+  return shard_score_impl(o, in, u_in, 0, true, tuple);
 }
 
 int smpc_oracle_shard_combine(smpc_oracle * o, const float * tuples, uint32_t n_tuples,

@@ -59,6 +59,8 @@ int smpc_oracle_shard_furthest(smpc_oracle* o, const smpc_tick_in* in, const flo
                                float* furthest);
 int smpc_oracle_shard_score(smpc_oracle* o, const smpc_tick_in* in, const float* u_in,
                             uint32_t furthest, float* tuple);
+int smpc_oracle_shard_rescore_failed(smpc_oracle* o, const smpc_tick_in* in,
+                                     const float* u_in, float* tuple);
 int smpc_oracle_shard_combine(smpc_oracle* o, const float* tuples, uint32_t n_tuples,
                               float* u_out, smpc_tick_out* out);
 

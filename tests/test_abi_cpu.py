@@ -1,0 +1,101 @@
+"""No-GPU checks of the drop-in boundary: libsmpc.so loads, exports every symbol
+include/smpc.h declares, its plain-C structs match the ctypes mirror, and the
+product refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mpcholonavigation_amd import _abi as A
+from mpcholonavigation_amd.tick import default_config, default_critics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from mpcholonavigation_amd.optimizer import load_library
+    return load_library()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "smpc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smpc_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in smpc.h but not exported"
+        assert name in A.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert sorted(A.PROTOTYPES) == declared
+
+
+def test_abi_version_and_defaults(lib):
+    assert lib.smpc_abi_version() == A.SMPC_ABI_VERSION
+    assert b"gfx950" in lib.smpc_build_info()
+    c = A.SmpcConfig()
+    lib.smpc_config_default(C.byref(c))
+    d = default_config()
+    for name, _ in A.SmpcConfig._fields_:
+        assert getattr(c, name) == getattr(d, name), name
+    p = A.SmpcCriticParams()
+    lib.smpc_critic_params_default(C.byref(p))
+    assert bytes(p) == bytes(default_critics())
+
+
+def test_struct_layout_matches_header():
+    """sizeof/offsetof of the ctypes mirror against a tiny C program compiled from smpc.h."""
+    import subprocess
+    import tempfile
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "smpc.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(smpc_config), sizeof(smpc_critic_params),
+         sizeof(smpc_tick_in), sizeof(smpc_tick_out));
+  printf("%zu %zu %zu %zu\n", offsetof(smpc_config, shard_offset), offsetof(smpc_tick_in, path_x),
+         offsetof(smpc_tick_in, fail_flag_in), offsetof(smpc_tick_out, score_pass_ms));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, src], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [int(x) for x in out]
+    assert sizes[:4] == [C.sizeof(A.SmpcConfig), C.sizeof(A.SmpcCriticParams),
+                         C.sizeof(A.SmpcTickIn), C.sizeof(A.SmpcTickOut)]
+    assert sizes[4:] == [A.SmpcConfig.shard_offset.offset, A.SmpcTickIn.path_x.offset,
+                         A.SmpcTickIn.fail_flag_in.offset, A.SmpcTickOut.score_pass_ms.offset]
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device smpc_create fails loudly (SMPC_ERR_DEVICE); with one this
+    test is skipped — the GPU suite covers the working path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mpcholonavigation_amd.optimizer import Smpc, SmpcError
+    with pytest.raises(SmpcError) as e:
+        Smpc(default_config(batch_size=64, time_steps=8))
+    assert e.value.code == A.SMPC_ERR_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under mpcholonavigation_amd/ imports, loads, links or calls oracle/."""
+    pkg = os.path.join(ROOT, "mpcholonavigation_amd")
+    bad = re.compile(r"import\s+oracle|from\s+oracle|liboracle|smpc_oracle_|oracle/|oracle\.loader")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(txt), (dirpath, f)

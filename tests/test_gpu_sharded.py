@@ -1,0 +1,98 @@
+"""Batch sharding on ONE GPU: G contexts each own a slice of the rollout batch; the
+shard phases of the C-ABI run on each, the tuples are combined on device.  The
+result must equal the unsharded GPU tick and the oracle (the N>1 data path
+without the collectives, which tests/test_sharded_cpu.py covers over gloo)."""
+import numpy as np
+import pytest
+import torch
+
+from mpcholonavigation_amd import _abi as A
+from mpcholonavigation_amd.synthetic import make_noise, make_scenario
+from mpcholonavigation_amd.tick import default_config, default_critics
+from tests.helpers import assert_parity, configure, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(cls, cfg, scn, noise, rows):
+    o = cls(cfg)
+    configure(o, scn, noise=[n[rows] for n in noise])
+    return o
+
+
+@pytest.mark.parametrize("G,B,T", [(2, 4096, 64), (8, 8192, 64), (3, 3000, 56)])
+def test_emulated_shards_match_unsharded(G, B, T):
+    from mpcholonavigation_amd.optimizer import Smpc
+    from oracle.loader import Oracle
+    scn = make_scenario(T)
+    noise = make_noise(B, T)
+    whole = _mk(Smpc, default_config(batch_size=B, time_steps=T), scn, noise, slice(0, B))
+    orc = _mk(Oracle, default_config(batch_size=B, time_steps=T), scn, noise, slice(0, B))
+    u_w, out_w = whole.optimize(scn.tick, scn.u0)
+    u_o, out_o = orc.optimize(scn.tick, scn.u0)
+    cuts = np.linspace(0, B, G + 1).astype(int)
+    shards = [_mk(Smpc, default_config(batch_size=int(b - a), time_steps=T, shard_offset=int(a),
+                                       global_batch_size=B), scn, noise, slice(a, b))
+              for a, b in zip(cuts[:-1], cuts[1:])]
+    dev = torch.device("cuda", 0)
+    L = shards[0].tuple_len
+    t_f = torch.zeros(G, dtype=torch.float32, device=dev)
+    t_all = torch.zeros(G * L, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for s in shards:
+        s.set_stream(stream)
+        s.shard_begin(scn.tick, scn.u0)
+    for g, s in enumerate(shards):
+        s.shard_furthest(t_f[g:].data_ptr())
+    t_max = t_f.max().reshape(1).contiguous()         # stands in for all_reduce(MAX)
+    for g, s in enumerate(shards):
+        s.shard_score(t_max.data_ptr(), 0, t_all[g * L:].data_ptr())
+    u_s, out_s = shards[0].shard_combine(t_all.data_ptr(), G)
+    assert out_s.furthest_reached_path_point == out_w.furthest_reached_path_point
+    assert out_s.non_colliding == out_w.non_colliding == out_o.non_colliding
+    assert rel_err(u_s, u_w) < 2e-6        # same kernels, different reduction tree
+    assert_parity(u_s, out_s, u_o, out_o, label=f"{G} shards vs oracle")
+    # speculative score with the right hint gives the same tuple; a wrong hint reports the truth
+    S = int(out_w.furthest_reached_path_point)
+    for g, s in enumerate(shards):
+        s.shard_score(0, S, t_all[g * L:].data_ptr())
+    u_h, out_h = shards[0].shard_combine(t_all.data_ptr(), G)
+    assert rel_err(u_h, u_s) < 1e-6
+    for g, s in enumerate(shards):
+        s.shard_score(0, max(S - 5, 0), t_all[g * L:].data_ptr())
+    _, out_m = shards[0].shard_combine(t_all.data_ptr(), G)
+    assert out_m.furthest_reached_path_point == S
+
+
+def test_sharded_driver_single_rank_gpu():
+    """ShardedOptimizer + HipShard with world_size 1 (no process group): exact and speculative."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    from mpcholonavigation_amd.sharded import HipShard, ShardedOptimizer
+    from oracle.loader import Oracle
+    B, T = 4096, 64
+    scn = make_scenario(T)
+    noise = make_noise(B, T)
+    torch.cuda.set_device(0)
+    orc = _mk(Oracle, default_config(batch_size=B, time_steps=T), scn, noise, slice(0, B))
+    for spec in (False, True):
+        g = _mk(Smpc, default_config(batch_size=B, time_steps=T), scn, noise, slice(0, B))
+        so = ShardedOptimizer(HipShard(g), speculate=spec)
+        u = uo = scn.u0
+        for k in range(3):
+            u, out = so.optimize(scn.tick, u)
+            uo, oo = orc.optimize(scn.tick, uo)
+            assert_parity(u, out, uo, oo, label=f"spec={spec} tick {k}")
+            uo = u.copy()
+
+
+def test_gpu_shard_rng_is_a_slice_of_the_global_stream():
+    from mpcholonavigation_amd.optimizer import Smpc
+    B, T = 200, 33
+    whole = Smpc(default_config(batch_size=B, time_steps=T))
+    whole.seed(7)
+    full = whole.get_noise()
+    for a, b in ((0, 67), (67, 200)):
+        sh = Smpc(default_config(batch_size=b - a, time_steps=T, shard_offset=a, global_batch_size=B))
+        sh.seed(7)
+        for x, y in zip(sh.get_noise(), full):
+            assert np.array_equal(x, y[a:b])
