@@ -257,6 +257,11 @@ int smpc_set_noise(smpc_ctx* ctx, const float* noise_vx, const float* noise_vy,
  * its second draw, optimizer.cpp:52-54). */
 int smpc_seed(smpc_ctx* ctx, uint64_t seed);
 
+/* NoiseGenerator::generateNextNoises() with regenerate_noises = true
+ * [ref src/noise_generator.cpp:54-63,97-105]: draw the next epoch's noise now
+ * (device-RNG mode only; constraints and costs are left alone). */
+int smpc_redraw_noise(smpc_ctx* ctx);
+
 /* Copy the ctx's noise tensors back (tests / RNG parity). Any pointer may be NULL. */
 int smpc_get_noise(smpc_ctx* ctx, float* noise_vx, float* noise_vy, float* noise_wz);
 

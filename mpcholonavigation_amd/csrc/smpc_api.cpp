@@ -817,6 +817,15 @@ int smpc_seed(smpc_ctx* c, uint64_t seed)
   return draw_noise(c);
 }
 
+int smpc_redraw_noise(smpc_ctx* c)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (!c->rng_mode) return fail(c, SMPC_ERR_STATE, "smpc_redraw_noise needs device-RNG mode (smpc_seed)");
+  HIPCK(c, hipSetDevice(c->device));
+  c->epoch++;
+  return draw_noise(c);
+}
+
 int smpc_get_noise(smpc_ctx* c, float* nvx, float* nvy, float* nwz)
 {
   if (!c) return SMPC_ERR_INVALID;

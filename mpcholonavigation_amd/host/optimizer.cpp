@@ -1,0 +1,375 @@
+// optimizer.cpp — see optimizer.hpp.  Host orchestration of one
+// computeVelocityCommands() tick over the libsmpc C-ABI.
+#include "optimizer.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace sortham
+{
+
+namespace
+{
+void ck(smpc_ctx * ctx, int rc, const char * what)
+{
+  if (rc != SMPC_OK) {
+    throw std::runtime_error(std::string(what) + ": " + smpc_last_error(ctx));
+  }
+}
+}  // namespace
+
+Optimizer::~Optimizer() {shutdown();}
+
+void Optimizer::shutdown()
+{
+  if (ctx_) {
+    smpc_destroy(ctx_);
+    ctx_ = nullptr;
+  }
+}
+
+void Optimizer::setMotionModel(const std::string & model)
+{
+  // The reference offers DiffDrive, Omni and Ackermann (optimizer.cpp:412-426); this
+  // build's fused path is the holonomic one the north star names.
+  if (model == "Omni") {
+    return;
+  }
+  if (model == "DiffDrive" || model == "Ackermann") {
+    throw std::runtime_error(
+            "Model " + model + " is not on the MI355X path: only Omni (holonomic) is built");
+  }
+  throw std::runtime_error(
+          std::string(
+            "Model " + model + " is not valid! Valid options are DiffDrive, Omni, "
+            "or Ackermann"));
+}
+
+void Optimizer::setOffset(double controller_frequency)
+{
+  const double controller_period = 1.0 / controller_frequency;
+  constexpr double eps = 1e-6;
+  if ((controller_period + eps) < settings_.model_dt) {
+    // reference warns: "Controller period is less then model dt, consider setting it equal"
+  } else if (std::abs(controller_period - settings_.model_dt) < eps) {
+    settings_.shift_control_sequence = true;
+  } else {
+    throw std::runtime_error("Controller period more then model dt, set it equal to model dt");
+  }
+}
+
+void Optimizer::initialize(
+  const models::OptimizerSettings & settings, const std::string & motion_model,
+  double controller_frequency, const CriticsConfig & critics, bool regenerate_noises,
+  uint64_t noise_seed, int device)
+{
+  shutdown();
+  settings_ = settings;
+  settings_.constraints = settings_.base_constraints;
+  setMotionModel(motion_model);
+  setOffset(controller_frequency);
+  critics_ = critics;
+  regenerate_noises_ = regenerate_noises;
+  noise_seed_ = noise_seed;
+  device_ = device;
+
+  // CriticManager::loadCritics (critic_manager.cpp:42-60): the YAML list decides which
+  // critics exist; the ones outside the fused set cannot be scored here
+  auto & p = critics_.params;
+  p.obstacles.enabled = p.path_align.enabled = p.path_follow.enabled = 0;
+  p.goal_angle.enabled = p.prefer_forward.enabled = 0;
+  for (const auto & name : critics_.critics) {
+    if (name == "ObstaclesCritic") {
+      p.obstacles.enabled = 1;
+    } else if (name == "PathAlignCritic") {
+      p.path_align.enabled = 1;
+    } else if (name == "PathFollowCritic") {
+      p.path_follow.enabled = 1;
+    } else if (name == "GoalAngleCritic") {
+      p.goal_angle.enabled = 1;
+    } else if (name == "PreferForwardCritic") {
+      p.prefer_forward.enabled = 1;
+    } else {
+      throw std::runtime_error(
+              "Critic sortham::critics::" + name +
+              " is registered but not fused on the MI355X path (SURVEY.md §8(f) rank 1)");
+    }
+  }
+
+  smpc_config cfg;
+  smpc_config_default(&cfg);
+  cfg.batch_size = settings_.batch_size;
+  cfg.time_steps = settings_.time_steps;
+  cfg.iteration_count = settings_.iteration_count;
+  cfg.model_dt = settings_.model_dt;
+  cfg.temperature = settings_.temperature;
+  cfg.gamma = settings_.gamma;
+  cfg.vx_max = settings_.base_constraints.vx_max;
+  cfg.vx_min = settings_.base_constraints.vx_min;
+  cfg.vy_max = settings_.base_constraints.vy;
+  cfg.wz_max = settings_.base_constraints.wz;
+  cfg.vx_std = settings_.sampling_std.vx;
+  cfg.vy_std = settings_.sampling_std.vy;
+  cfg.wz_std = settings_.sampling_std.wz;
+  cfg.device = device_;
+  cfg.flags = visualize_ ? SMPC_FLAG_STORE_TRAJECTORIES : 0u;
+  int rc = smpc_create(&cfg, &ctx_);
+  if (rc != SMPC_OK) {
+    throw std::runtime_error(std::string("smpc_create: ") + smpc_last_error(nullptr));
+  }
+  ck(ctx_, smpc_set_critics(ctx_, &critics_.params), "smpc_set_critics");
+  // NoiseGenerator::initialize draws once (noise_generator.cpp:26-42) ...
+  ck(ctx_, smpc_seed(ctx_, noise_seed_), "smpc_seed");
+  // ... and Optimizer::initialize ends in reset(), which draws again (H7)
+  reset();
+}
+
+void Optimizer::pushConstraints()
+{
+  const auto & c = settings_.constraints;
+  ck(ctx_, smpc_set_constraints(ctx_, c.vx_max, c.vx_min, c.vy, c.wz), "smpc_set_constraints");
+}
+
+void Optimizer::reset()
+{
+  control_sequence_.reset(settings_.time_steps);
+  control_history_[0] = {0.0f, 0.0f, 0.0f};
+  control_history_[1] = {0.0f, 0.0f, 0.0f};
+  control_history_[2] = {0.0f, 0.0f, 0.0f};
+  control_history_[3] = {0.0f, 0.0f, 0.0f};
+  settings_.constraints = settings_.base_constraints;
+  if (ctx_) {
+    ck(ctx_, smpc_reset(ctx_), "smpc_reset");   // costs, noise re-draw (noise_generator.cpp:76-95)
+  }
+}
+
+void Optimizer::setCostmap(const CostmapView & m)
+{
+  const bool infl = m.has_inflation_layer;
+  ck(
+    ctx_, smpc_set_costmap(
+      ctx_, m.cells, m.size_x, m.size_y, m.origin_x, m.origin_y, m.resolution,
+      m.track_unknown ? 1 : 0, m.inscribed_radius, infl ? critics_.cost_scaling_factor : 0.0f,
+      infl ? critics_.inflation_radius : 0.0f), "smpc_set_costmap");
+}
+
+void Optimizer::setNoise(const float * nvx, const float * nvy, const float * nwz)
+{
+  ck(ctx_, smpc_set_noise(ctx_, nvx, nvy, nwz), "smpc_set_noise");
+  supplied_noise_ = true;
+}
+
+void Optimizer::prepare(
+  const Pose2D & robot_pose, const Twist2D & robot_speed, const models::Path & plan,
+  const Pose2D & goal)
+{
+  pose_ = robot_pose;
+  speed_ = robot_speed;
+  path_ = plan;
+  goal_ = goal;
+  fail_flag_ = false;   // costs_.fill(0) and the CriticData caches are per smpc_optimize call
+}
+
+void Optimizer::optimize()
+{
+  smpc_tick_in in;
+  std::memset(&in, 0, sizeof(in));
+  in.pose_x = pose_.x;
+  in.pose_y = pose_.y;
+  in.pose_yaw = static_cast<float>(pose_.yaw);   // float initial_yaw = tf2::getYaw(...)
+  in.speed_vx = speed_.vx;
+  in.speed_vy = speed_.vy;
+  in.speed_wz = speed_.wz;
+  in.path_x = path_.x.data();
+  in.path_y = path_.y.data();
+  in.path_yaw = path_.yaws.data();
+  in.path_len = static_cast<uint32_t>(path_.x.size());
+  in.goal_x = goal_.x;
+  in.goal_y = goal_.y;
+  in.path_pts_valid = nullptr;
+  in.fail_flag_in = fail_flag_ ? 1 : 0;   // sticky across the retry (critic_manager.cpp:70-73)
+
+  const unsigned int T = settings_.time_steps;
+  std::vector<float> u(3 * T);
+  std::memcpy(u.data(), control_sequence_.vx.data(), T * sizeof(float));
+  std::memcpy(u.data() + T, control_sequence_.vy.data(), T * sizeof(float));
+  std::memcpy(u.data() + 2 * T, control_sequence_.wz.data(), T * sizeof(float));
+  pushConstraints();
+  ck(ctx_, smpc_optimize(ctx_, &in, u.data(), &last_out_), "smpc_optimize");
+  std::memcpy(control_sequence_.vx.data(), u.data(), T * sizeof(float));
+  std::memcpy(control_sequence_.vy.data(), u.data() + T, T * sizeof(float));
+  std::memcpy(control_sequence_.wz.data(), u.data() + 2 * T, T * sizeof(float));
+  fail_flag_ = last_out_.fail_flag != 0;
+  if (regenerate_noises_ && !supplied_noise_) {
+    // NoiseGenerator::generateNextNoises (noise_generator.cpp:54-63): next tick's noise
+    ck(ctx_, smpc_redraw_noise(ctx_), "smpc_redraw_noise");
+  }
+}
+
+bool Optimizer::fallback(bool fail)
+{
+  if (!fail) {
+    retry_counter_ = 0;
+    return false;
+  }
+  reset();
+  if (++retry_counter_ > settings_.retry_attempt_limit) {
+    retry_counter_ = 0;
+    throw std::runtime_error("Optimizer fail to compute path");
+  }
+  return true;
+}
+
+Twist2D Optimizer::evalControl(
+  const Pose2D & robot_pose, const Twist2D & robot_speed, const models::Path & plan,
+  const Pose2D & goal)
+{
+  prepare(robot_pose, robot_speed, plan, goal);
+  do {
+    optimize();
+  } while (fallback(fail_flag_));
+  utils::savitskyGolayFilter(control_sequence_, control_history_, settings_);
+  auto control = getControlFromSequenceAsTwist();
+  if (settings_.shift_control_sequence) {
+    shiftControlSequence();
+  }
+  return control;
+}
+
+void Optimizer::shiftControlSequence()
+{
+  auto roll = [](std::vector<float> & v) {
+      if (v.size() < 2) {
+        return;
+      }
+      for (size_t i = 0; i + 1 < v.size(); ++i) {
+        v[i] = v[i + 1];
+      }
+      v[v.size() - 1] = v[v.size() - 2];
+    };
+  roll(control_sequence_.vx);
+  roll(control_sequence_.wz);
+  roll(control_sequence_.vy);   // isHolonomic()
+}
+
+Twist2D Optimizer::getControlFromSequenceAsTwist()
+{
+  const unsigned int offset = settings_.shift_control_sequence ? 1 : 0;
+  Twist2D t;
+  t.vx = control_sequence_.vx.at(offset);
+  t.wz = control_sequence_.wz.at(offset);
+  t.vy = control_sequence_.vy.at(offset);
+  return t;
+}
+
+void Optimizer::setSpeedLimit(double speed_limit, bool percentage)
+{
+  auto & s = settings_;
+  constexpr double NO_SPEED_LIMIT = 0.0;   // nav2_costmap_2d filter_values.hpp
+  if (speed_limit == NO_SPEED_LIMIT) {
+    s.constraints = s.base_constraints;
+  } else {
+    const double ratio = percentage ? speed_limit / 100.0 : speed_limit / s.base_constraints.vx_max;
+    s.constraints.vx_max = s.base_constraints.vx_max * ratio;
+    s.constraints.vx_min = s.base_constraints.vx_min * ratio;
+    s.constraints.vy = s.base_constraints.vy * ratio;
+    s.constraints.wz = s.base_constraints.wz * ratio;
+  }
+}
+
+std::vector<std::array<float, 3>> Optimizer::getOptimizedTrajectory()
+{
+  // integrateStateVelocities(trajectory, sequence) — optimizer.cpp:275-311: the control
+  // sequence itself is integrated (no measured-speed first column here)
+  const unsigned int T = settings_.time_steps;
+  const float dt = settings_.model_dt;
+  const float initial_yaw = static_cast<float>(pose_.yaw);
+  std::vector<std::array<float, 3>> traj(T);
+  std::vector<float> yaws(T);
+  float acc = 0.0f;
+  for (unsigned int t = 0; t < T; ++t) {
+    const float inc = control_sequence_.wz[t] * dt;
+    acc = t == 0 ? inc : acc + inc;
+    yaws[t] = acc + initial_yaw;
+  }
+  float ax = 0.0f, ay = 0.0f;
+  for (unsigned int t = 0; t < T; ++t) {
+    const float c = t == 0 ? cosf(initial_yaw) : cosf(yaws[t - 1]);
+    const float s = t == 0 ? sinf(initial_yaw) : sinf(yaws[t - 1]);
+    float dx = control_sequence_.vx[t] * c;
+    float dy = control_sequence_.vx[t] * s;
+    dx = dx - control_sequence_.vy[t] * s;
+    dy = dy + control_sequence_.vy[t] * c;
+    ax = t == 0 ? dx * dt : ax + dx * dt;
+    ay = t == 0 ? dy * dt : ay + dy * dt;
+    traj[t] = {static_cast<float>(pose_.x + static_cast<double>(ax)),
+      static_cast<float>(pose_.y + static_cast<double>(ay)), yaws[t]};
+  }
+  return traj;
+}
+
+void Optimizer::getGeneratedTrajectories(
+  std::vector<float> & x, std::vector<float> & y, std::vector<float> & yaws)
+{
+  const size_t n = static_cast<size_t>(settings_.batch_size) * settings_.time_steps;
+  x.resize(n);
+  y.resize(n);
+  yaws.resize(n);
+  ck(ctx_, smpc_get_trajectories(ctx_, x.data(), y.data(), yaws.data()), "smpc_get_trajectories");
+}
+
+namespace utils
+{
+
+void savitskyGolayFilter(
+  models::ControlSequence & control_sequence, std::array<models::Control, 4> & control_history,
+  const models::OptimizerSettings & settings)
+{
+  // Savitzky-Golay quadratic, 9 points: {-21,14,39,54,59,54,39,14,-21}/231, applied in
+  // place front to back; the first four outputs lean on the last four executed controls,
+  // the tail repeats the last sample; index T-5 is left as is (the reference's loop ends
+  // one short and then steps over it, tools/utils.hpp:518-533)
+  const unsigned int n = static_cast<unsigned int>(control_sequence.vx.size());
+  if (n == 0 || n - 1 < 20) {
+    return;
+  }
+  const unsigned int last = n - 1;
+  float w[9] = {-21.0f, 14.0f, 39.0f, 54.0f, 59.0f, 54.0f, 39.0f, 14.0f, -21.0f};
+  for (float & c : w) {
+    c /= 231.0f;
+  }
+  auto run = [&](std::vector<float> & q, float h0, float h1, float h2, float h3) {
+      const float hist[4] = {h0, h1, h2, h3};
+      // sample at signed position i: history for i < 0, clamped to `last` beyond the end
+      auto at = [&](int i) -> float {
+          if (i < 0) {
+            return hist[4 + i];
+          }
+          return q[static_cast<unsigned int>(i) > last ? last : static_cast<unsigned int>(i)];
+        };
+      for (unsigned int idx = 0; idx <= last; ++idx) {
+        if (idx == last - 4) {
+          continue;
+        }
+        float acc = 0.0f;
+        for (int k = 0; k < 9; ++k) {
+          acc += at(static_cast<int>(idx) + k - 4) * w[k];
+        }
+        q[idx] = acc;
+      }
+    };
+  const auto & h = control_history;
+  run(control_sequence.vx, h[0].vx, h[1].vx, h[2].vx, h[3].vx);
+  run(control_sequence.vy, h[0].vy, h[1].vy, h[2].vy, h[3].vy);
+  run(control_sequence.wz, h[0].wz, h[1].wz, h[2].wz, h[3].wz);
+  const unsigned int offset = settings.shift_control_sequence ? 1 : 0;
+  control_history[0] = control_history[1];
+  control_history[1] = control_history[2];
+  control_history[2] = control_history[3];
+  control_history[3] = {control_sequence.vx[offset], control_sequence.vy[offset],
+    control_sequence.wz[offset]};
+}
+
+}  // namespace utils
+}  // namespace sortham

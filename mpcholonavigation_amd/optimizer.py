@@ -105,6 +105,9 @@ class Smpc:
     def seed(self, seed):
         self._ck(self.lib.smpc_seed(self.h, seed))
 
+    def redraw_noise(self):
+        self._ck(self.lib.smpc_redraw_noise(self.h))
+
     def get_noise(self):
         out = [np.empty((self.B, self.T), np.float32) for _ in range(3)]
         self._ck(self.lib.smpc_get_noise(self.h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))

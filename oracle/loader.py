@@ -68,6 +68,19 @@ _PROTOTYPES = {
     "smpc_oracle_philox4x32_10": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "smpc_config_default": (None, [C.POINTER(A.SmpcConfig)]),
     "smpc_critic_params_default": (None, [C.POINTER(A.SmpcCriticParams)]),
+    "smpc_oracle_opt_create": (C.c_int, [C.POINTER(A.SmpcConfig), C.POINTER(A.SmpcCriticParams),
+                                         C.c_double, C.c_uint32, C.POINTER(_ctx)]),
+    "smpc_oracle_opt_destroy": (None, [_ctx]),
+    "smpc_oracle_opt_core": (_ctx, [_ctx]),
+    "smpc_oracle_opt_last_error": (C.c_char_p, [_ctx]),
+    "smpc_oracle_opt_eval_control": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), C.c_void_p,
+                                               C.POINTER(A.SmpcTickOut)]),
+    "smpc_oracle_opt_set_speed_limit": (C.c_int, [_ctx, C.c_double, C.c_int]),
+    "smpc_oracle_opt_reset": (C.c_int, [_ctx]),
+    "smpc_oracle_opt_get_control_sequence": (C.c_int, [_ctx, _f32p]),
+    "smpc_oracle_opt_set_control_sequence": (C.c_int, [_ctx, _f32p]),
+    "smpc_oracle_opt_get_constraints": (C.c_int, [_ctx, _f32p, C.POINTER(C.c_int32)]),
+    "smpc_oracle_opt_get_optimized_trajectory": (C.c_int, [_ctx, _f32p]),
 }
 
 _libs = {}
@@ -208,3 +221,80 @@ class Oracle:
         self._ck(self.lib.smpc_oracle_shard_combine(self.h, ptr(tuples), n, ptr(u),
                                                     C.byref(out)))
         return u, out
+
+
+class OracleOptimizer:
+    """Host half of sortham::Optimizer on the oracle (smpc_oracle_host.cpp)."""
+
+    THROWN = -10
+
+    def __init__(self, cfg, critics, controller_frequency, retry_attempt_limit=1):
+        self.lib = load()
+        self.T, self.B = cfg.time_steps, cfg.batch_size
+        h = _ctx()
+        rc = self.lib.smpc_oracle_opt_create(C.byref(cfg), C.byref(critics), controller_frequency,
+                                             retry_attempt_limit, C.byref(h))
+        if rc == self.THROWN:
+            raise RuntimeError("Controller period more then model dt, set it equal to model dt")
+        if rc != 0:
+            raise RuntimeError(f"smpc_oracle_opt_create: {rc}")
+        self.h = h
+        self.core = _ctx(self.lib.smpc_oracle_opt_core(h))
+
+    def close(self):
+        if self.h:
+            self.lib.smpc_oracle_opt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_costmap(self, cells, origin_x, origin_y, resolution, track_unknown=False,
+                    inscribed_radius=0.1, cost_scaling_factor=10.0, inflation_radius=0.55):
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        h, w = cells.shape
+        assert self.lib.smpc_oracle_set_costmap(
+            self.core, ptr(cells), w, h, origin_x, origin_y, resolution, int(track_unknown),
+            inscribed_radius, cost_scaling_factor, inflation_radius) == 0
+
+    def set_noise(self, nvx, nvy, nwz):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (nvx, nvy, nwz)]
+        assert self.lib.smpc_oracle_set_noise(self.core, ptr(a[0]), ptr(a[1]), ptr(a[2])) == 0
+
+    def eval_control(self, tick):
+        tw = np.zeros(3, np.float64)
+        out = A.SmpcTickOut()
+        rc = self.lib.smpc_oracle_opt_eval_control(self.h, C.byref(tick.c), ptr(tw), C.byref(out))
+        if rc == self.THROWN:
+            raise RuntimeError(self.lib.smpc_oracle_opt_last_error(self.h).decode())
+        assert rc == 0, rc
+        return tw, out
+
+    def set_speed_limit(self, limit, percentage):
+        assert self.lib.smpc_oracle_opt_set_speed_limit(self.h, limit, int(percentage)) == 0
+
+    def reset(self):
+        assert self.lib.smpc_oracle_opt_reset(self.h) == 0
+
+    def get_control_sequence(self):
+        u = np.zeros((3, self.T), np.float32)
+        assert self.lib.smpc_oracle_opt_get_control_sequence(self.h, ptr(u)) == 0
+        return u
+
+    def set_control_sequence(self, u):
+        u = np.ascontiguousarray(u, np.float32)
+        assert self.lib.smpc_oracle_opt_set_control_sequence(self.h, ptr(u)) == 0
+
+    def get_constraints(self):
+        c = np.zeros(4, np.float32)
+        s = C.c_int32(0)
+        assert self.lib.smpc_oracle_opt_get_constraints(self.h, ptr(c), C.byref(s)) == 0
+        return c, bool(s.value)
+
+    def get_optimized_trajectory(self):
+        t = np.zeros((self.T, 3), np.float32)
+        assert self.lib.smpc_oracle_opt_get_optimized_trajectory(self.h, ptr(t)) == 0
+        return t

@@ -118,6 +118,24 @@ void smpc_oracle_speed_limit(const float* base, double speed_limit, int percenta
 /* returns 0 = warn (period < dt), 1 = shift on, -1 = throws */
 int smpc_oracle_set_offset(double controller_frequency, float model_dt);
 
+/* ---- host half of sortham::Optimizer (smpc_oracle_host.cpp) -------------------
+ * eval_control returns -10 where the reference throws std::runtime_error. */
+typedef struct smpc_oracle_opt smpc_oracle_opt;
+int smpc_oracle_opt_create(const smpc_config* base, const smpc_critic_params* critics,
+                           double controller_frequency, uint32_t retry_attempt_limit,
+                           smpc_oracle_opt** out);
+void smpc_oracle_opt_destroy(smpc_oracle_opt* o);
+smpc_oracle* smpc_oracle_opt_core(smpc_oracle_opt* o);
+const char* smpc_oracle_opt_last_error(const smpc_oracle_opt* o);
+int smpc_oracle_opt_eval_control(smpc_oracle_opt* o, const smpc_tick_in* in, double* twist,
+                                 smpc_tick_out* out);
+int smpc_oracle_opt_set_speed_limit(smpc_oracle_opt* o, double speed_limit, int percentage);
+int smpc_oracle_opt_reset(smpc_oracle_opt* o);
+int smpc_oracle_opt_get_control_sequence(smpc_oracle_opt* o, float* u);
+int smpc_oracle_opt_set_control_sequence(smpc_oracle_opt* o, const float* u);
+int smpc_oracle_opt_get_constraints(smpc_oracle_opt* o, float* c4, int32_t* shift);
+int smpc_oracle_opt_get_optimized_trajectory(smpc_oracle_opt* o, float* xyyaw);
+
 /* Philox4x32-10 block (counter c[4], key k[2]) -> out[4]; RNG pinning */
 void smpc_oracle_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
 
