@@ -6,7 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 
-namespace sortham
+namespace SORTHAM_HOST_NS
 {
 
 namespace
@@ -372,4 +372,4 @@ void savitskyGolayFilter(
 }
 
 }  // namespace utils
-}  // namespace sortham
+}  // namespace SORTHAM_HOST_NS

@@ -18,7 +18,14 @@
 
 #include "../../include/smpc.h"
 
-namespace sortham
+// The class is sortham::Optimizer, like the reference's.  Inside the Nav2 package the
+// ROS-typed adaptor of the same name wraps it (nav2_plugin/), which then builds this file
+// with -DSORTHAM_HOST_NS=sortham_host.
+#ifndef SORTHAM_HOST_NS
+#define SORTHAM_HOST_NS sortham
+#endif
+
+namespace SORTHAM_HOST_NS
 {
 
 namespace models
@@ -178,6 +185,6 @@ protected:
   smpc_tick_out last_out_{};
 };
 
-}  // namespace sortham
+}  // namespace SORTHAM_HOST_NS
 
 #endif

@@ -1,4 +1,4 @@
-// optimizer_c.cpp — extern "C" face of sortham::Optimizer (include/smpc_host.h).
+// optimizer_c.cpp — extern "C" face of sortham_ns::Optimizer (include/smpc_host.h).
 #include <cstring>
 #include <exception>
 #include <new>
@@ -7,9 +7,11 @@
 #include "../../include/smpc_host.h"
 #include "optimizer.hpp"
 
+namespace sortham_ns = SORTHAM_HOST_NS;
+
 struct sortham_optimizer
 {
-  sortham::Optimizer opt;
+  sortham_ns::Optimizer opt;
   std::string err;
 };
 
@@ -50,7 +52,7 @@ int sortham_optimizer_create(
   }
   int rc = guarded(
     nullptr, [&]() {
-      sortham::models::OptimizerSettings s;
+      sortham_ns::models::OptimizerSettings s;
       const smpc_config & b = cfg->base;
       s.base_constraints = {b.vx_max, b.vx_min, b.vy_max, b.wz_max};
       s.sampling_std = {b.vx_std, b.vy_std, b.wz_std};
@@ -61,7 +63,7 @@ int sortham_optimizer_create(
       s.time_steps = b.time_steps;
       s.iteration_count = b.iteration_count;
       s.retry_attempt_limit = cfg->retry_attempt_limit;
-      sortham::CriticsConfig cc;
+      sortham_ns::CriticsConfig cc;
       cc.params = *critics;
       for (uint32_t i = 0; i < cfg->n_critics && i < 16; ++i) {
         cc.critics.emplace_back(cfg->critics[i] ? cfg->critics[i] : "");
@@ -96,7 +98,7 @@ int sortham_optimizer_set_costmap(
   if (!o) {return SMPC_ERR_INVALID;}
   return guarded(
     o, [&]() {
-      sortham::CostmapView m;
+      sortham_ns::CostmapView m;
       m.cells = cells;
       m.size_x = width;
       m.size_y = height;
@@ -123,14 +125,14 @@ int sortham_optimizer_eval_control(
   if (!o || !in || !twist_out) {return SMPC_ERR_INVALID;}
   return guarded(
     o, [&]() {
-      sortham::Pose2D pose{in->pose_x, in->pose_y, static_cast<double>(in->pose_yaw)};
-      sortham::Pose2D goal{in->goal_x, in->goal_y, 0.0};
-      sortham::Twist2D speed{in->speed_vx, in->speed_vy, in->speed_wz};
-      sortham::models::Path plan;
+      sortham_ns::Pose2D pose{in->pose_x, in->pose_y, static_cast<double>(in->pose_yaw)};
+      sortham_ns::Pose2D goal{in->goal_x, in->goal_y, 0.0};
+      sortham_ns::Twist2D speed{in->speed_vx, in->speed_vy, in->speed_wz};
+      sortham_ns::models::Path plan;
       plan.x.assign(in->path_x, in->path_x + in->path_len);
       plan.y.assign(in->path_y, in->path_y + in->path_len);
       plan.yaws.assign(in->path_yaw, in->path_yaw + in->path_len);
-      const sortham::Twist2D t = o->opt.evalControl(pose, speed, plan, goal);
+      const sortham_ns::Twist2D t = o->opt.evalControl(pose, speed, plan, goal);
       twist_out[0] = t.vx;
       twist_out[1] = t.vy;
       twist_out[2] = t.wz;
@@ -200,17 +202,17 @@ int sortham_optimizer_get_optimized_trajectory(sortham_optimizer * o, float * xy
 
 void sortham_utils_savitsky_golay(float * u, uint32_t T, float * history, int shift)
 {
-  sortham::models::ControlSequence cs;
+  sortham_ns::models::ControlSequence cs;
   cs.vx.assign(u, u + T);
   cs.vy.assign(u + T, u + 2 * T);
   cs.wz.assign(u + 2 * T, u + 3 * T);
-  std::array<sortham::models::Control, 4> h;
+  std::array<sortham_ns::models::Control, 4> h;
   for (int i = 0; i < 4; ++i) {
     h[i] = {history[3 * i], history[3 * i + 1], history[3 * i + 2]};
   }
-  sortham::models::OptimizerSettings s;
+  sortham_ns::models::OptimizerSettings s;
   s.shift_control_sequence = shift != 0;
-  sortham::utils::savitskyGolayFilter(cs, h, s);
+  sortham_ns::utils::savitskyGolayFilter(cs, h, s);
   std::memcpy(u, cs.vx.data(), T * sizeof(float));
   std::memcpy(u + T, cs.vy.data(), T * sizeof(float));
   std::memcpy(u + 2 * T, cs.wz.data(), T * sizeof(float));

@@ -1,0 +1,138 @@
+// fused_critics.cpp — the twelve sortham::critics::* classes critics.xml registers.
+// Compiled only inside a ROS 2 Humble + Nav2 workspace (needs the reference package's
+// critic_function.hpp, pluginlib, nav2_costmap_2d); NOT built by this repository's
+// tests — see INTEGRATION.md.
+//
+// The five critics on the MI355X path read exactly the parameters their reference
+// initialize() reads (same names, same defaults) and publish them to
+// FusedCriticRegistry; score() does nothing because libsmpc scores inside the
+// fused kernel.  The other seven stay loadable but refuse to be configured, so a
+// YAML that lists them fails loudly instead of silently dropping a cost term.
+#include <stdexcept>
+#include <string>
+
+#include "nav2_sortham_controller/critic_function.hpp"   // from the reference package
+#include "nav2_sortham_controller/fused_critic_registry.hpp"
+
+namespace sortham::critics
+{
+
+namespace
+{
+// name_ is "<controller>.<CriticName>" (critic_manager.cpp:55-57)
+std::string controller_of(const std::string & full)
+{
+  const auto dot = full.rfind('.');
+  return dot == std::string::npos ? full : full.substr(0, dot);
+}
+}  // namespace
+
+#define FUSED_CRITIC_BEGIN(Class)                                   \
+  class Class : public CriticFunction                               \
+  {                                                                 \
+public:                                                             \
+    void score(CriticData &) override {}                            \
+    void initialize() override                                      \
+    {                                                               \
+      auto getParam = parameters_handler_->getParamGetter(name_);   \
+      auto & e = FusedCriticRegistry::get().entry(controller_of(name_));
+
+#define FUSED_CRITIC_END }                                          \
+  };
+
+FUSED_CRITIC_BEGIN(ObstaclesCritic)   // ref src/critics/obstacles_critic.cpp:21-31,76-80
+auto & p = e.params.obstacles;
+bool consider_footprint = false;
+p.enabled = enabled_;
+getParam(consider_footprint, "consider_footprint", false);
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.repulsion_weight, "repulsion_weight", 1.5);
+getParam(p.critical_weight, "critical_weight", 20.0);
+getParam(p.collision_cost, "collision_cost", 10000.0);
+getParam(p.collision_margin_distance, "collision_margin_distance", 0.10);
+getParam(p.near_goal_distance, "near_goal_distance", 0.5);
+getParam(e.cost_scaling_factor, "cost_scaling_factor", 10.0);
+getParam(e.inflation_radius, "inflation_radius", 0.55);
+p.consider_footprint = consider_footprint;
+if (consider_footprint) {
+  throw std::runtime_error(
+          "ObstaclesCritic: consider_footprint=true is not on the MI355X path yet");
+}
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(PathAlignCritic)   // ref src/critics/path_align_critic.cpp:26-38
+auto & p = e.params.path_align;
+bool use_path_orientations = false;
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 10.0);
+getParam(p.max_path_occupancy_ratio, "max_path_occupancy_ratio", 0.07);
+getParam(p.offset_from_furthest, "offset_from_furthest", 20);
+getParam(p.trajectory_point_step, "trajectory_point_step", 4);
+getParam(p.threshold_to_consider, "threshold_to_consider", 0.5);
+getParam(use_path_orientations, "use_path_orientations", false);
+p.use_path_orientations = use_path_orientations;
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(PathFollowCritic)  // ref src/critics/path_follow_critic.cpp:23-33
+auto & p = e.params.path_follow;
+p.enabled = enabled_;
+getParam(p.threshold_to_consider, "threshold_to_consider", 1.4);
+getParam(p.offset_from_furthest, "offset_from_furthest", 6);
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 5.0);
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(GoalAngleCritic)   // ref src/critics/goal_angle_critic.cpp:20-27
+auto & p = e.params.goal_angle;
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 3.0);
+getParam(p.threshold_to_consider, "threshold_to_consider", 0.5);
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(PreferForwardCritic)  // ref src/critics/prefer_forward_critic.cpp:20-27
+auto & p = e.params.prefer_forward;
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 5.0);
+getParam(p.threshold_to_consider, "threshold_to_consider", 0.5);
+FUSED_CRITIC_END
+
+#define UNFUSED_CRITIC(Class)                                                                  \
+  class Class : public CriticFunction                                                          \
+  {                                                                                            \
+public:                                                                                        \
+    void score(CriticData &) override {}                                                       \
+    void initialize() override                                                                 \
+    {                                                                                          \
+      throw std::runtime_error(                                                                \
+              #Class " is registered but not fused on the MI355X path (SURVEY.md §8(f) rank 1)"); \
+    }                                                                                          \
+  };
+
+UNFUSED_CRITIC(CostCritic)
+UNFUSED_CRITIC(GoalCritic)
+UNFUSED_CRITIC(PathAlignLegacyCritic)
+UNFUSED_CRITIC(PathAngleCritic)
+UNFUSED_CRITIC(TwirlingCritic)
+UNFUSED_CRITIC(ConstraintCritic)
+UNFUSED_CRITIC(VelocityDeadbandCritic)
+
+}  // namespace sortham::critics
+
+#include <pluginlib/class_list_macros.hpp>
+
+#define EXPORT(Class) PLUGINLIB_EXPORT_CLASS(sortham::critics::Class, sortham::critics::CriticFunction)
+EXPORT(ObstaclesCritic)
+EXPORT(CostCritic)
+EXPORT(GoalCritic)
+EXPORT(GoalAngleCritic)
+EXPORT(PathAlignCritic)
+EXPORT(PathAlignLegacyCritic)
+EXPORT(PathAngleCritic)
+EXPORT(PathFollowCritic)
+EXPORT(PreferForwardCritic)
+EXPORT(TwirlingCritic)
+EXPORT(ConstraintCritic)
+EXPORT(VelocityDeadbandCritic)
