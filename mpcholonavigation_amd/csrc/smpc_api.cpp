@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -204,7 +205,10 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
   L.off_D = o; o += pf;
   L.off_valid = o; o += align_up(std::max(P, 1u), 16);
   L.off_scr = o;
-  L.scr_stride = align_up(4 + 3 * T, 4);
+  // per wave: x/y/yaw of the current rollout [3T] (re-used for the block combine [4+3T])
+  // followed by the 2x64 ring of parked endpoints
+  L.scr_ring = align_up(4 + 3 * T, 4);
+  L.scr_stride = L.scr_ring + 128;
   o += nwave * L.scr_stride * 4;
   L.total = o;
   return L;
@@ -505,6 +509,10 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     c->occ_mode = mode_now;
   }
   uint32_t per_cu = std::min(c->occ_blocks, 32u / waves_per_block);
+  if (const char* e = getenv("SMPC_MAX_BLOCKS_PER_CU")) {   // tuning knob
+    const uint32_t lim = static_cast<uint32_t>(atoi(e));
+    if (lim >= 1) per_cu = std::min(per_cu, lim);
+  }
   uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));

@@ -90,6 +90,7 @@ struct SmpcDev {
 struct SmpcLds {
   uint32_t off_lut, off_px, off_py, off_pyaw, off_D, off_valid, off_scr;
   uint32_t scr_stride;  // floats per wave of scratch
+  uint32_t scr_ring;    // float offset of the 2x64 endpoint ring inside a wave's scratch
   uint32_t total;       // bytes
 };
 

@@ -40,16 +40,54 @@ __device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v)
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
 
-// inclusive + scan over the 64 lanes (all lanes must be active)
+// Inclusive + scan over the 64 lanes (all lanes must be active): Kogge–Stone inside the
+// 16-lane DPP rows, then row_bcast:15 / :31 carry the row totals.  Written as one asm
+// block so that every step is a single v_add_f32_dpp (hipcc leaves the two broadcast steps
+// as mov + add + re-zeroing) and the VALU-write -> DPP-read wait states are explicit.
+#define SCAN_STEP1(op, ctl) op " %0, %0, %0 " ctl "\n\t"
 __device__ __forceinline__ float wave_scan_add(float v)
 {
-  v += dpp_f<0x111>(0.f, v);        // row_shr:1
-  v += dpp_f<0x112>(0.f, v);        // row_shr:2
-  v += dpp_f<0x114>(0.f, v);        // row_shr:4
-  v += dpp_f<0x118>(0.f, v);        // row_shr:8
-  v += dpp_f<0x142, 0xA>(0.f, v);   // row_bcast:15 -> rows 1,3
-  v += dpp_f<0x143, 0xC>(0.f, v);   // row_bcast:31 -> rows 2,3
+  asm volatile(
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    : "+v"(v));
   return v;
+}
+// two independent scans interleaved: one wait state between dependent steps instead of two
+__device__ __forceinline__ void wave_scan_add2(float& a, float& b)
+{
+  asm volatile(
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 0\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 0\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 0\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 0\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+    "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+    "s_nop 0\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+    "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -62,17 +100,6 @@ __device__ __forceinline__ double wave_sum_d(double v)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
 }
-__device__ __forceinline__ float wave_min(float v)
-{
-  const float inf = __int_as_float(0x7f800000);
-  v = fminf(v, dpp_f<0x111>(inf, v));
-  v = fminf(v, dpp_f<0x112>(inf, v));
-  v = fminf(v, dpp_f<0x114>(inf, v));
-  v = fminf(v, dpp_f<0x118>(inf, v));
-  v = fminf(v, dpp_f<0x142, 0xA>(inf, v));
-  v = fminf(v, dpp_f<0x143, 0xC>(inf, v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
 __device__ __forceinline__ uint32_t wave_min_u(uint32_t v)
 {
   v = min(v, dpp_u<0x111>(0xffffffffu, v));
@@ -82,6 +109,11 @@ __device__ __forceinline__ uint32_t wave_min_u(uint32_t v)
   v = min(v, dpp_u<0x142, 0xA>(0xffffffffu, v));
   v = min(v, dpp_u<0x143, 0xC>(0xffffffffu, v));
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// min of non-negative floats: unsigned min of the bit patterns (one v_min_u32_dpp per step)
+__device__ __forceinline__ float wave_min_nonneg(float v)
+{
+  return __uint_as_float(wave_min_u(__float_as_uint(v)));
 }
 // value of lane-1 (lane 0 gets `first`)
 __device__ __forceinline__ float wave_shr1(float v, float first)
@@ -192,6 +224,37 @@ __device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const uint8_t* s_m
   uint32_t c = s_map[inw ? ly * p.win_w + lx : 0u];
   if (__builtin_expect(!inw, 0)) c = p.map[(size_t)my * p.W + mx];
   return c;
+}
+
+// max over the parked endpoints of argmin_j |path_j - endpoint|^2 (first minimum wins)
+__device__ __forceinline__ uint32_t flush_endpoint_ring(const float* ring_x, const float* ring_y,
+                                                        uint32_t n, const float* s_px,
+                                                        const float* s_py, uint32_t P, int lane)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool on = (uint32_t)lane < n;
+  const float ex = on ? ring_x[lane] : 0.f, ey = on ? ring_y[lane] : 0.f;
+  float best = 3.4028234663852886e38f;  // numeric_limits<float>::max()
+  uint32_t bi = 0;
+  for (uint32_t j = 0; j < P; ++j) {
+    const float ddx = s_px[j] - ex, ddy = s_py[j] - ey;
+    const float d = ddx * ddx + ddy * ddy;
+    if (d < best) {
+      best = d;
+      bi = j;
+    }
+  }
+  uint32_t m = on ? bi : 0u;
+  m = max(m, dpp_u<0x111>(0u, m));
+  m = max(m, dpp_u<0x112>(0u, m));
+  m = max(m, dpp_u<0x114>(0u, m));
+  m = max(m, dpp_u<0x118>(0u, m));
+  m = max(m, dpp_u<0x142, 0xA>(0u, m));
+  m = max(m, dpp_u<0x143, 0xC>(0u, m));
+  __builtin_amdgcn_wave_barrier();
+  return (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
 }
 
 // ---------------------------------------------------------------------------
@@ -310,6 +373,9 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 #pragma unroll
   for (int r = 0; r < R; ++r) Ux[r] = Uy[r] = Uz[r] = 0.f;
   uint32_t S_local = 0, n_noncoll = 0;
+  float* ring_x = scr + L.scr_ring;   // parked rollout endpoints (see below)
+  float* ring_y = ring_x + WAVE;
+  uint32_t n_ring = 0;
 
   const uint32_t gw = blockIdx.x * nwave + wave;
   const uint32_t nW = gridDim.x * nwave;
@@ -396,8 +462,10 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
         c_prev = cs[r];
         s_prev = sn[r];
       }
-      const float ex = wave_shr1(wave_scan_add(ax), 0.f);
-      const float ey = wave_shr1(wave_scan_add(ay), 0.f);
+      float sx = ax, sy = ay;
+      wave_scan_add2(sx, sy);
+      const float ex = wave_shr1(sx, 0.f);
+      const float ey = wave_shr1(sy, 0.f);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         x[r] = (float)(p.x0 + (double)(ex + x[r]));
@@ -427,29 +495,21 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- nearest path point of the endpoint (utils.hpp:292-319) -----------
+    // Only max_b argmin_j matters and nothing in this rollout's cost depends on it, so
+    // the endpoints are parked in a 64-slot LDS ring and resolved 64 rollouts at a time
+    // with lane = rollout (sequential j loop: the reference's first-minimum order).
     if (want_local_furthest) {
-      const float ex = scr_x[T - 1], ey = scr_y[T - 1];
-      float best = 3.4028234663852886e38f;  // numeric_limits<float>::max()
-      uint32_t bi = 0xffffffffu;
-      for (uint32_t j = lane; j < p.P; j += WAVE) {
-        const float ddx = s_px[j] - ex, ddy = s_py[j] - ey;
-        const float d = ddx * ddx + ddy * ddy;
-        if (d < best) {
-          best = d;
-          bi = j;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if ((uint32_t)(t0 + r) == T - 1) {
+          ring_x[n_ring] = x[r];
+          ring_y[n_ring] = y[r];
         }
       }
-      const float gbest = wave_min(best);
-      // first index attaining the minimum; none (all >= FLT_MAX / NaN) -> 0
-      uint32_t a_b;
-      if (p.P <= WAVE) {
-        const unsigned long long hit = __ballot(best == gbest && bi != 0xffffffffu);
-        a_b = hit ? (uint32_t)(__ffsll((long long)hit) - 1) : 0u;   // index == lane
-      } else {
-        a_b = wave_min_u((best == gbest && bi != 0xffffffffu) ? bi : 0xffffffffu);
-        if (a_b == 0xffffffffu) a_b = 0;
+      if (++n_ring == WAVE) {
+        S_local = max(S_local, flush_endpoint_ring(ring_x, ring_y, WAVE, s_px, s_py, p.P, lane));
+        n_ring = 0;
       }
-      S_local = max(S_local, a_b);
     }
     if (FURTHEST_ONLY) continue;
 
@@ -588,11 +648,14 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 
     // ---- PathFollowCritic (path_follow_critic.cpp:56-70) ---------------------
     if (p.flags & SD_PATH_FOLLOW) {
-      const double ddx = (double)(scr_x[T - 1] - pf_x);
-      const double ddy = (double)(scr_y[T - 1] - pf_y);
-      const double dist = sqrt(ddx * ddx + ddy * ddy);
-      if (GENERIC) cost = add_cost_pow(cost, (double)p.pf_weight * dist, p.pf_power);
-      else uni += (float)((double)p.pf_weight * dist);
+      const float fdx = scr_x[T - 1] - pf_x, fdy = scr_y[T - 1] - pf_y;
+      if (GENERIC) {
+        const double ddx = (double)fdx, ddy = (double)fdy;
+        const double dist = sqrt(ddx * ddx + ddy * ddy);
+        cost = add_cost_pow(cost, (double)p.pf_weight * dist, p.pf_power);
+      } else {
+        uni += p.pf_weight * fast_sqrt(fdx * fdx + fdy * fdy);
+      }
     }
 
     // ---- GoalAngleCritic (goal_angle_critic.cpp:36-50) -----------------------
@@ -654,6 +717,9 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     m_run = m_new;
     __builtin_amdgcn_wave_barrier();
   }
+
+  if (want_local_furthest && n_ring)
+    S_local = max(S_local, flush_endpoint_ring(ring_x, ring_y, n_ring, s_px, s_py, p.P, lane));
 
   // ---- block combine -> one partial per block --------------------------------
   __syncthreads();

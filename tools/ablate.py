@@ -15,7 +15,8 @@ names = ["obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward
 sets = {"none": [], "obstacles": ["obstacles"], "path_align": ["path_align"],
         "path_follow": ["path_follow"], "prefer_forward": ["prefer_forward"],
         "all": names}
-cfg = default_config(batch_size=B, time_steps=T, flags=A.SMPC_FLAG_PROFILE)
+EXTRA = int(os.environ.get('SMPC_ABLATE_FLAGS', '0'))
+cfg = default_config(batch_size=B, time_steps=T, flags=A.SMPC_FLAG_PROFILE | EXTRA)
 scn = make_scenario(T, map_size=MAP)
 g = Smpc(cfg)
 g.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
