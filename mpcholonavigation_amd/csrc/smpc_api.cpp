@@ -24,7 +24,8 @@
 
 hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
                             uint32_t grid, uint32_t block, hipStream_t st);
-hipError_t smpc_pass_occupancy(int R, int mode, uint32_t block, uint32_t lds_bytes, int* blocks_per_cu);
+hipError_t smpc_pass_occupancy(int R, int mode, bool full, uint32_t block, uint32_t lds_bytes,
+                               int* blocks_per_cu);
 hipError_t smpc_set_pass_lds_limit(int bytes);
 hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
                               float neg_inv_temp, float* tuple, hipStream_t st);
@@ -41,7 +42,8 @@ thread_local std::string g_create_error;
 
 constexpr uint32_t kBlock = 512;          // threads per block of the streaming pass
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
-constexpr uint32_t kWindowBytes = 65536;  // costmap window staged in LDS
+constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
+                                           // 0.05 m around the robot; the rest is read from HBM/L2
 constexpr uint32_t kLdsPerCu = 160 * 1024;
 
 inline uint32_t align_up(uint32_t v, uint32_t a) {return (v + a - 1) / a * a;}
@@ -192,8 +194,9 @@ TickLayout tick_layout(uint32_t T, uint32_t P)
   return l;
 }
 
-// LDS carve-up of the streaming pass
-SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map)
+// LDS carve-up of the streaming pass.  nsamp = PathAlign samples per rollout (0: off).
+SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
+                 uint32_t nsamp = 0)
 {
   SmpcLds L{};
   uint32_t o = with_map ? align_up(window_bytes, 16) : 0;
@@ -205,10 +208,18 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
   L.off_D = o; o += pf;
   L.off_valid = o; o += align_up(std::max(P, 1u), 16);
   L.off_scr = o;
-  // per wave: x/y/yaw of the current rollout [3T] (re-used for the block combine [4+3T])
-  // followed by the 2x64 ring of parked endpoints
-  L.scr_ring = align_up(4 + 3 * T, 4);
-  L.scr_stride = L.scr_ring + 128;
+  // lanes per parked rollout: sample slots 0..nsamp fit one segment of 16/32/64 lanes;
+  // rollouts per flush: as many segments as a wave has, capped so that the parked
+  // controls stay <= 3 KiB per wave
+  const uint32_t R = T <= 64 ? 1 : (T <= 128 ? 2 : 4);
+  L.seg_shift = nsamp + 1 <= 16 ? 4 : (nsamp + 1 <= 32 ? 5 : 6);
+  L.group = std::max(1u, std::min(64u >> L.seg_shift, 4u / R));
+  // per wave: [sample points 3x64][endpoint ring 2x64][parked controls group x 3T]; the head is
+  // re-used for the block combine [4+3T]
+  L.scr_pts = 0;
+  L.scr_ring = 3 * 64;
+  L.scr_c = L.scr_ring + 2 * 64;
+  L.scr_stride = align_up(std::max(L.scr_c + L.group * 3 * T, 4 + 3 * T), 4);
   o += nwave * L.scr_stride * 4;
   L.total = o;
   return L;
@@ -233,6 +244,13 @@ void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut)
   for (int v = 0; v < 256; ++v) {
     lut[v].crit = 0.f;
     lut[v].rep = 0.f;
+    // inCollision (obstacles_critic.cpp:185-201), consider_footprint = false
+    if (v == SMPC_COST_LETHAL || v == SMPC_COST_INSCRIBED ||
+      (v == SMPC_COST_NO_INFORMATION && !m.track_unknown))
+    {
+      lut[v].crit = -1.0f;                                   // :152 collision marker
+      continue;
+    }
     if (v < 1) continue;                                     // :150 free space
     if (m.inflation_radius == 0.0f || m.cost_scaling_factor == 0.0f) continue;  // :155
     const float d = distance_to_obstacle(m, static_cast<float>(v));
@@ -307,9 +325,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   const uint32_t step = cr.path_align.trajectory_point_step;
   if (gates & SD_PATH_ALIGN) {
     nsamp = step > 0 ? (T - 1) / step : 0;
-    if (nsamp > 64)
+    if (nsamp > 63)
       return fail(c, SMPC_ERR_UNSUPPORTED,
-                  "PathAlign: more than 64 samples per trajectory (time_steps / trajectory_point_step)");
+                  "PathAlign: more than 63 samples per trajectory (time_steps / trajectory_point_step)");
     if (nsamp == 0) gates &= ~SD_PATH_ALIGN;  // no samples: cost 0 for every rollout
     if (cr.path_align.use_path_orientations) gates |= SD_USE_PATH_YAW;
   }
@@ -483,7 +501,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   uint32_t window_bytes = 0;
   if (c->map.set && (gates & SD_OBSTACLES)) {
     uint32_t side = 4;
-    while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 256 for 64 KiB
+    while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 96 cells
     const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
     long cx = static_cast<long>((in->pose_x - c->map.ox) / c->map.res);
     long cy = static_cast<long>((in->pose_y - c->map.oy) / c->map.res);
@@ -495,7 +513,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     d.win_w = static_cast<int32_t>(ww); d.win_h = static_cast<int32_t>(wh);
     window_bytes = ww * wh;
   }
-  c->lds = make_lds(window_bytes, P, T, kBlock / 64, window_bytes != 0);
+  c->lds = make_lds(window_bytes, P, T, kBlock / 64, window_bytes != 0, nsamp);
   if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
 
   // persistent grid: as many blocks as stay resident, never more than the work
@@ -503,7 +521,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   const int mode_now = c->score_mode_for(cr);
   if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
     int nb = 0;
-    if (smpc_pass_occupancy(c->R, mode_now, kBlock, c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
+    if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), kBlock, c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
     c->occ_blocks = static_cast<uint32_t>(nb);
     c->occ_lds = c->lds.total;
     c->occ_mode = mode_now;

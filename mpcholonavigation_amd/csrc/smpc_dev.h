@@ -21,8 +21,8 @@
 #define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
 
 struct SmpcLut {  // per 8-bit cost: {margin - d | 0, R_infl - d | 0}  (obstacles_critic.cpp:159-170)
-  float crit;
-  float rep;
+  float crit;        // < 0 marks inCollision(cost) (obstacles_critic.cpp:185-201); a real
+  float rep;         // margin - d is always > 0
 };
 
 struct SmpcDev {
@@ -90,7 +90,11 @@ struct SmpcDev {
 struct SmpcLds {
   uint32_t off_lut, off_px, off_py, off_pyaw, off_D, off_valid, off_scr;
   uint32_t scr_stride;  // floats per wave of scratch
-  uint32_t scr_ring;    // float offset of the 2x64 endpoint ring inside a wave's scratch
+  uint32_t scr_pts;     // float offsets inside a wave's scratch: sample points [3][64],
+  uint32_t scr_ring;    //   parked endpoints [2][64],
+  uint32_t scr_c;       //   parked noised controls [group][3][T]
+  uint32_t seg_shift;   // log2 of the lanes per parked rollout in the flush (4, 5 or 6)
+  uint32_t group;       // rollouts parked per flush
   uint32_t total;       // bytes
 };
 

@@ -115,6 +115,17 @@ __device__ __forceinline__ float wave_min_nonneg(float v)
 {
   return __uint_as_float(wave_min_u(__float_as_uint(v)));
 }
+// shr1(src) + addend in ONE instruction: lane l gets src[l-1] + addend[l], lane 0 gets
+// 0 + addend[0] (bound_ctrl).  With addend = {first, 0, 0, ...} it is the reference's
+// "column 0 is the initial value, column t is the previous column" shift.
+__device__ __forceinline__ float dpp_shr1_add(float src, float addend)
+{
+  float d;
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+               : "=v"(d) : "v"(src), "v"(addend));
+  return d;
+}
 // value of lane-1 (lane 0 gets `first`)
 __device__ __forceinline__ float wave_shr1(float v, float first)
 {
@@ -257,6 +268,52 @@ __device__ __forceinline__ uint32_t flush_endpoint_ring(const float* ring_x, con
   return (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
 }
 
+// float min over the wave (any sign): one v_min_f32_dpp per step, no canonicalisation
+__device__ __forceinline__ float wave_min_f(float v)
+{
+  asm volatile(
+    "s_nop 1\n\t"
+    "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
+    : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// inclusive + scan inside segments of 16 << (seg_shift - 4) lanes (16, 32 or 64)
+__device__ __forceinline__ float seg_scan_add(float v, uint32_t seg_shift)
+{
+  asm volatile(
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "s_nop 1\n\t"
+    : "+v"(v));
+  if (seg_shift >= 5) {
+    asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 : "+v"(v));
+  }
+  if (seg_shift >= 6) {
+    asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1\n\t"
+                 : "+v"(v));
+  }
+  return v;
+}
+
 // ---------------------------------------------------------------------------
 // The streaming pass.
 //   MODE 0: score, every cost_power == 1 (the defaults): all per-step terms of
@@ -264,8 +321,15 @@ __device__ __forceinline__ uint32_t flush_endpoint_ring(const float* ring_x, con
 //   MODE 1: rollout + endpoint argmin only (utils::findPathFurthestReachedPoint,
 //           tools/utils.hpp:292-319)
 //   MODE 2: score, general cost_power (pow in double per critic)
+//   FULL:   T == 64*R, every lane owns R valid steps (no tail predicates)
+//
+// A wave rolls out one rollout at a time (lane = time step) and PARKS it: its noised
+// controls go to an LDS ring, its PathAlign sample points to a slot table, its cost so
+// far to a lane slot.  Every L.group rollouts the wave FLUSHES: PathAlign for the whole
+// group with lane = (rollout, sample) so all 64 lanes work, one shared softmax rescale,
+// then the weighted controls of the group are accumulated.
 // ---------------------------------------------------------------------------
-template <int R, int MODE>
+template <int R, int MODE, bool FULL>
 __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pass(const SmpcDev p, const SmpcLds L)
 {
   constexpr bool FURTHEST_ONLY = MODE == 1;
@@ -284,9 +348,12 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
   const int wave = tid >> 6;
   const int nwave = blockDim.x >> 6;
   float* scr = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
-  float* scr_x = scr;
-  float* scr_y = scr + p.T;
-  float* scr_yaw = scr + 2 * p.T;
+  float* pts_x = scr + L.scr_pts;        // [64] PathAlign sample points, slot = g*SEG + s
+  float* pts_y = pts_x + WAVE;
+  float* pts_yaw = pts_y + WAVE;
+  float* ring_x = scr + L.scr_ring;      // [64] parked rollout endpoints
+  float* ring_y = ring_x + WAVE;
+  float* cring = scr + L.scr_c;          // [group][3][T] parked noised controls
 
   // ---- stage costmap window, LUT and path into LDS -------------------------
   if (!FURTHEST_ONLY && (p.flags & SD_OBSTACLES)) {
@@ -325,15 +392,20 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
   // ---- per-lane constants --------------------------------------------------
   const uint32_t T = p.T;
   const int t0 = lane * R;
+#define STEP_OK(r) (FULL || (uint32_t)(t0 + (r)) < T)
   float uvx[R], uvy[R], uwz[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const bool a = (uint32_t)(t0 + r) < T;
+    const bool a = STEP_OK(r);
     uvx[r] = a ? p.u[t0 + r] : 0.f;
     uvy[r] = a ? p.u[T + t0 + r] : 0.f;
     uwz[r] = a ? p.u[2 * T + t0 + r] : 0.f;
   }
   const float dt = p.dt;
+  // {initial value in lane 0, 0 elsewhere}: addends of the fused shift (dpp_shr1_add)
+  const float first_vx = lane == 0 ? p.svx : 0.f, first_vy = lane == 0 ? p.svy : 0.f;
+  const float first_wz = lane == 0 ? p.swz : 0.f;
+  const float first_cos = lane == 0 ? p.cos0 : 0.f, first_sin = lane == 0 ? p.sin0 : 0.f;
   float gux[R], guy[R], guz[R];   // gamma/std^2 * u (optimizer.cpp:367-379), MODE 0
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -363,9 +435,18 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
   }
   const bool want_local_furthest =
     FURTHEST_ONLY || ((p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST));
-  // PathAlign sample of this lane: trajectory points q and q - step
-  const uint32_t pa_q = ((uint32_t)lane + 1u) * p.step;
-  const bool pa_smp = (uint32_t)lane < p.nsamp;
+  // group geometry: GROUP rollouts parked per flush, SEG lanes (sample slots) per rollout
+  const uint32_t seg_shift = L.seg_shift, SEG = 1u << seg_shift, GROUP = L.group;
+  const uint32_t K = p.nsamp;   // PathAlign samples: trajectory points step, 2 step, ..., K step
+  // sample slot of each step this lane owns: t = s*step, s = 0..K  (-1: not a sample)
+  int slot[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t t = t0 + r;
+    const uint32_t q = p.step ? t / p.step : 0u;
+    slot[r] = (pa_on && p.step && STEP_OK(r) && q * p.step == t && q <= K) ? (int)q : -1;
+  }
+  const uint32_t end_lane = (T - 1) / R, end_r = (T - 1) % R;
 
   // running softmax state of this wave (optimizer.cpp:382-391 as an online sum)
   float m_run = 3.0e38f, s_run = 0.f;
@@ -373,12 +454,146 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 #pragma unroll
   for (int r = 0; r < R; ++r) Ux[r] = Uy[r] = Uz[r] = 0.f;
   uint32_t S_local = 0, n_noncoll = 0;
-  float* ring_x = scr + L.scr_ring;   // parked rollout endpoints (see below)
-  float* ring_y = ring_x + WAVE;
-  uint32_t n_ring = 0;
+  uint32_t n_ring = 0, n_pend = 0;
+  float pend_cost = 0.f;        // lanes of segment g: cost so far of parked rollout g
 
   const uint32_t gw = blockIdx.x * nwave + wave;
   const uint32_t nW = gridDim.x * nwave;
+
+  // flush of the parked group: PathAlign, costs, softmax, weighted controls
+  auto flush = [&](uint32_t n, uint32_t b_last) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t g = (uint32_t)lane >> seg_shift, s = (uint32_t)lane & (SEG - 1);
+    const bool rowon = g < n;
+    float cost = pend_cost;
+    // ---- PathAlignCritic (path_align_critic.cpp:92-135), lane = (rollout g, sample s) ----
+    if (pa_on) {
+      const bool smp = rowon && s >= 1 && s <= K;
+      const float Tx = pts_x[lane], Ty = pts_y[lane];
+      const float Qx = wave_shr1(Tx, 0.f), Qy = wave_shr1(Ty, 0.f);   // previous sample point
+      float chord = 0.f;
+      if (smp) {
+        const float ddx = Tx - Qx, ddy = Ty - Qy;
+        chord = GENERIC ? sqrtf(ddx * ddx + ddy * ddy) : fast_sqrt(ddx * ddx + ddy * ddy);
+      }
+      const float dist = seg_scan_add(chord, seg_shift);
+      // std::lower_bound over D[0..S).  Plans are close to uniformly spaced, so the
+      // index is guessed from the mean spacing and confirmed against D[g-1], D[g],
+      // D[g+1]; a wave with any unconfirmed lane runs the branch-free binary search.
+      uint32_t gi = (uint32_t)(dist * pa_inv_spacing);
+      gi = gi < S ? gi : S - 1;
+      const float da = gi > 0 ? s_D[gi - 1] : -3.0e38f;
+      const float db = s_D[gi];
+      const float dc = gi + 1 < S ? s_D[gi + 1] : 3.0e38f;
+      uint32_t lo;
+      float dl, dh;   // D[lo-1], D[lo]
+      const bool at_g = da < dist && !(db < dist);
+      const bool at_g1 = db < dist && !(dc < dist);
+      if (at_g) {
+        lo = gi; dl = da; dh = db;
+      } else {
+        lo = gi + 1; dl = db; dh = dc;
+      }
+      if (__builtin_expect(__any(!(at_g || at_g1)), 0)) {
+        uint32_t base = 0, nn = S;
+        for (uint32_t it = 0; it < bs_iters; ++it) {
+          const uint32_t half = nn >> 1;
+          base = (s_D[base + half - 1 + (half == 0)] < dist && half) ? base + half : base;
+          nn -= half;
+        }
+        const float d_base = s_D[base];
+        lo = base + (d_base < dist ? 1u : 0u);
+        dl = lo > 0 ? s_D[lo - 1] : 0.f;
+        dh = lo < S ? s_D[lo] : 0.f;
+      }
+      uint32_t cand;
+      if (lo >= S) {
+        cand = S - 1;  // reference dereferences end(): defined as size-1 (SURVEY H1)
+      } else if (lo == 0) {
+        cand = 0;
+      } else {
+        cand = (dist - dl < dh - dist) ? lo - 1 : lo;
+      }
+      // findClosestPathPt's `iter == begin + init -> return 0` chains through path_pt:
+      // path_pt_k = 0 where lo_k == path_pt_{k-1}.  With E_k = (lo_k == cand_{k-1} != 0 ...)
+      // the chain F_k = E_k & ~F_{k-1} is "every other bit of each run of ones"; slot 0 of
+      // a segment is never a sample, so runs do not cross rollouts.
+      uint32_t cand_v = cand;
+      asm volatile("" : "+v"(cand_v));   // DPP sources must sit in a VGPR
+      const uint32_t cand_prev = dpp_u<0x138>(0u, cand_v);   // wave_shr:1
+      unsigned long long E = __ballot(smp && lo == cand_prev && cand != 0u);
+      uint32_t pt = cand;
+      if (E) {
+        unsigned long long F = E & ~(E << 1);
+        unsigned long long M = E & (E << 1);
+        F |= (F << 2) & M;
+        M &= M << 2;
+        F |= (F << 4) & M;
+        M &= M << 4;
+        F |= (F << 8) & M;
+        M &= M << 8;
+        F |= (F << 16) & M;
+        M &= M << 16;
+        F |= (F << 32) & M;
+        if ((F >> lane) & 1ull) pt = 0;
+      }
+      const bool ok = smp && s_valid[pt];
+      float d = 0.f;
+      if (ok) {
+        const float ddx = s_px[pt] - Tx, ddy = s_py[pt] - Ty;
+        if (p.flags & SD_USE_PATH_YAW) {
+          const double dd = (double)pts_yaw[lane] - (double)s_pyaw[pt];
+          double a = fmod(fmod(dd, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+          if (a > M_PI) a -= 2.0 * M_PI;
+          const float dyaw = (float)a;
+          d = sqrtf(ddx * ddx + ddy * ddy + dyaw * dyaw);
+        } else {
+          d = GENERIC ? sqrtf(ddx * ddx + ddy * ddy) : fast_sqrt(ddx * ddx + ddy * ddy);
+        }
+      }
+      // per-rollout sum and count: last lane of the segment after a segmented scan
+      const float dsum = seg_scan_add(d, seg_shift);
+      const float summed = __shfl(dsum, lane | (int)(SEG - 1), WAVE);
+      const unsigned long long okm = __ballot(ok) >> (g << seg_shift);
+      const unsigned long long segm = SEG == 64 ? ~0ull : ((1ull << SEG) - 1ull);
+      const float num = (float)__popcll(okm & segm);
+      const float c_pa = num > 0.f ? (GENERIC ? summed / num : summed * fast_rcp(num)) : 0.f;
+      if (GENERIC) cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
+      else cost += c_pa * p.pa_weight;
+    }
+    // costs_ [B]: one lane per parked rollout
+    if (rowon && s == 0) p.costs[b_last - (n - 1 - g) * nW] = cost;
+
+    // ---- softmax over the group (optimizer.cpp:382-391 as an online sum) ----------
+    const float cmin = wave_min_f(rowon ? cost : 3.0e38f);
+    const float m_new = fminf(m_run, cmin);
+    // exp(-(c - m)/temperature) as one v_exp_f32: 2^(k2 (c - m)), k2 = -log2(e)/temperature
+    const float f = __builtin_amdgcn_exp2f(p.k2 * (m_run - m_new));   // rescale old sums (<= 1)
+    const float w = rowon ? __builtin_amdgcn_exp2f(p.k2 * (cost - m_new)) : 0.f;
+    s_run = fmaf(s_run, f, wave_sum(s == 0 ? w : 0.f));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      Ux[r] *= f;
+      Uy[r] *= f;
+      Uz[r] *= f;
+    }
+    for (uint32_t gg = 0; gg < n; ++gg) {
+      const float wg = lane_bcast(w, (int)(gg << seg_shift));
+      const float* cg = cring + (size_t)gg * 3 * T;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          Ux[r] = fmaf(wg, cg[t0 + r], Ux[r]);
+          Uy[r] = fmaf(wg, cg[T + t0 + r], Uy[r]);
+          Uz[r] = fmaf(wg, cg[2 * T + t0 + r], Uz[r]);
+        }
+      }
+    }
+    m_run = m_new;
+    __builtin_amdgcn_wave_barrier();
+  };
 
   // noise rows are prefetched one rollout ahead
   float n0[R], n1[R], n2[R];
@@ -386,14 +601,16 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     const size_t row = (size_t)gw * T;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const bool a = (uint32_t)(t0 + r) < T;
+      const bool a = STEP_OK(r);
       n0[r] = a ? p.nvx[row + t0 + r] : 0.f;
       n1[r] = a ? p.nvy[row + t0 + r] : 0.f;
       n2[r] = a ? p.nwz[row + t0 + r] : 0.f;
     }
   }
 
+  uint32_t b_prev = gw;
   for (uint32_t b = gw; b < p.B; b += nW) {
+    b_prev = b;
     // ---- NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74) -----
     const size_t row = (size_t)b * T;
     float cvx[R], cvy[R], cwz[R];
@@ -407,7 +624,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       const size_t nrow = (size_t)(b + nW) * T;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const bool a = (uint32_t)(t0 + r) < T;
+        const bool a = STEP_OK(r);
         n0[r] = a ? p.nvx[nrow + t0 + r] : 0.f;
         n1[r] = a ? p.nvy[nrow + t0 + r] : 0.f;
         n2[r] = a ? p.nwz[nrow + t0 + r] : 0.f;
@@ -415,18 +632,20 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     }
     // ---- updateStateVelocities + predict: v[:,0]=speed, v[:,1:]=c[:,:-1] ---
     float vx[R], vy[R], wz[R];
-    vx[0] = wave_shr1(cvx[R - 1], p.svx);
-    vy[0] = wave_shr1(cvy[R - 1], p.svy);
-    wz[0] = wave_shr1(cwz[R - 1], p.swz);
+    vx[0] = dpp_shr1_add(cvx[R - 1], first_vx);
+    vy[0] = dpp_shr1_add(cvy[R - 1], first_vy);
+    wz[0] = dpp_shr1_add(cwz[R - 1], first_wz);
 #pragma unroll
     for (int r = 1; r < R; ++r) {
       vx[r] = cvx[r - 1];
       vy[r] = cvy[r - 1];
       wz[r] = cwz[r - 1];
     }
+    if (!FULL) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if ((uint32_t)(t0 + r) >= T) vx[r] = vy[r] = wz[r] = 0.f;
+      for (int r = 0; r < R; ++r) {
+        if (!STEP_OK(r)) vx[r] = vy[r] = wz[r] = 0.f;
+      }
     }
     // ---- integrateStateVelocities (optimizer.cpp:313-343) -------------------
     float yaw[R];
@@ -438,9 +657,13 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
         acc += wz[r] * dt;
         yaw[r] = acc;
       }
-      const float excl = wave_shr1(wave_scan_add(acc), 0.f);
+      const float incl = wave_scan_add(acc);
+      if (R == 1) {
+        yaw[0] = incl + p.yaw0;   // one step per lane: the inclusive scan is the cumsum
+      } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) yaw[r] = (excl + yaw[r]) + p.yaw0;
+        for (int r = 0; r < R; ++r) yaw[r] = dpp_shr1_add(incl, yaw[r]) + p.yaw0;
+      }
     }
     float x[R], y[R];
     {
@@ -448,8 +671,8 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 #pragma unroll
       for (int r = 0; r < R; ++r) smpc_sincos(yaw[r], sn[r], cs[r]);
       // cos_[t] = cos(yaw[t-1]), cos_[0] = cosf(initial_yaw)
-      float c_prev = wave_shr1(cs[R - 1], p.cos0);
-      float s_prev = wave_shr1(sn[R - 1], p.sin0);
+      float c_prev = dpp_shr1_add(cs[R - 1], first_cos);
+      float s_prev = dpp_shr1_add(sn[R - 1], first_sin);
       float ax = 0.f, ay = 0.f;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -464,47 +687,50 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       }
       float sx = ax, sy = ay;
       wave_scan_add2(sx, sy);
-      const float ex = wave_shr1(sx, 0.f);
-      const float ey = wave_shr1(sy, 0.f);
+      if (R == 1) {
+        x[0] = (float)(p.x0 + (double)sx);
+        y[0] = (float)(p.y0 + (double)sy);
+      } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        x[r] = (float)(p.x0 + (double)(ex + x[r]));
-        y[r] = (float)(p.y0 + (double)(ey + y[r]));
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if ((uint32_t)(t0 + r) < T) {
-        scr_x[t0 + r] = x[r];
-        scr_y[t0 + r] = y[r];
-        if (!FURTHEST_ONLY && (p.flags & SD_USE_PATH_YAW)) scr_yaw[t0 + r] = yaw[r];
+        for (int r = 0; r < R; ++r) {
+          x[r] = (float)(p.x0 + (double)dpp_shr1_add(sx, x[r]));
+          y[r] = (float)(p.y0 + (double)dpp_shr1_add(sy, y[r]));
+        }
       }
     }
     if (!FURTHEST_ONLY && (p.flags & SD_STORE_TRAJ)) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if ((uint32_t)(t0 + r) < T) {
+        if (STEP_OK(r)) {
           p.traj_x[row + t0 + r] = x[r];
           p.traj_y[row + t0 + r] = y[r];
           p.traj_yaw[row + t0 + r] = yaw[r];
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // endpoint of the rollout (uniform): lane end_lane, step end_r
+    float ex, ey;
+    {
+      float xe = x[0], ye = y[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        if ((uint32_t)r == end_r) {
+          xe = x[r];
+          ye = y[r];
+        }
+      }
+      ex = lane_bcast(xe, (int)end_lane);
+      ey = lane_bcast(ye, (int)end_lane);
+    }
 
     // ---- nearest path point of the endpoint (utils.hpp:292-319) -----------
     // Only max_b argmin_j matters and nothing in this rollout's cost depends on it, so
     // the endpoints are parked in a 64-slot LDS ring and resolved 64 rollouts at a time
     // with lane = rollout (sequential j loop: the reference's first-minimum order).
     if (want_local_furthest) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if ((uint32_t)(t0 + r) == T - 1) {
-          ring_x[n_ring] = x[r];
-          ring_y[n_ring] = y[r];
-        }
+      if (lane == 0) {
+        ring_x[n_ring] = ex;
+        ring_y[n_ring] = ey;
       }
       if (++n_ring == WAVE) {
         S_local = max(S_local, flush_endpoint_ring(ring_x, ring_y, WAVE, s_px, s_py, p.P, lane));
@@ -523,15 +749,14 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       int first_r = R;  // first colliding step inside this lane
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if ((uint32_t)(t0 + r) < T && first_r == R) {
+        if (STEP_OK(r) && first_r == R) {
           // point 0 is the same for every rollout (v[:,0] is the measured speed): its
           // cell was looked up once on the host with the same arithmetic
           const uint32_t c = (t0 + r == 0) ? p.cost_t0 : cost_at(p, s_map, x[r], y[r]);
-          const bool collide = (c >= 253u) && !(c == 255u && (p.flags & SD_TRACK_UNKNOWN));
-          if (collide) {
+          const SmpcLut e = s_lut[c];
+          if (e.crit < 0.f) {   // inCollision
             first_r = r;
           } else {
-            const SmpcLut e = s_lut[c];
             crit += e.crit;
             rep += e.rep;
           }
@@ -556,99 +781,9 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       }
     }
 
-    // ---- PathAlignCritic (path_align_critic.cpp:92-135) ----------------------
-    if (pa_on) {
-      float Tx = 0.f, Ty = 0.f, chord = 0.f;
-      if (pa_smp) {
-        Tx = scr_x[pa_q];
-        Ty = scr_y[pa_q];
-        const float ddx = Tx - scr_x[pa_q - p.step], ddy = Ty - scr_y[pa_q - p.step];
-        chord = GENERIC ? sqrtf(ddx * ddx + ddy * ddy) : fast_sqrt(ddx * ddx + ddy * ddy);
-      }
-      const float dist = wave_scan_add(chord);
-      // std::lower_bound over D[0..S).  Plans are close to uniformly spaced, so the
-      // index is guessed from the mean spacing and confirmed against D[g-1], D[g],
-      // D[g+1]; a wave with any unconfirmed lane runs the branch-free binary search.
-      uint32_t g = (uint32_t)(dist * pa_inv_spacing);
-      g = g < S ? g : S - 1;
-      const float da = g > 0 ? s_D[g - 1] : -3.0e38f;
-      const float db = s_D[g];
-      const float dc = g + 1 < S ? s_D[g + 1] : 3.0e38f;
-      uint32_t lo;
-      float dl, dh;   // D[lo-1], D[lo]
-      const bool at_g = da < dist && !(db < dist);
-      const bool at_g1 = db < dist && !(dc < dist);
-      if (at_g) {
-        lo = g; dl = da; dh = db;
-      } else {
-        lo = g + 1; dl = db; dh = dc;
-      }
-      if (__builtin_expect(__any(!(at_g || at_g1)), 0)) {
-        uint32_t base = 0, n = S;
-        for (uint32_t it = 0; it < bs_iters; ++it) {
-          const uint32_t half = n >> 1;
-          base = (s_D[base + half - 1 + (half == 0)] < dist && half) ? base + half : base;
-          n -= half;
-        }
-        const float d_base = s_D[base];
-        lo = base + (d_base < dist ? 1u : 0u);
-        dl = lo > 0 ? s_D[lo - 1] : 0.f;
-        dh = lo < S ? s_D[lo] : 0.f;
-      }
-      uint32_t cand;
-      if (lo >= S) {
-        cand = S - 1;  // reference dereferences end(): defined as size-1 (SURVEY H1)
-      } else if (lo == 0) {
-        cand = 0;
-      } else {
-        cand = (dist - dl < dh - dist) ? lo - 1 : lo;
-      }
-      // findClosestPathPt's `iter == begin + init -> return 0` chains through path_pt:
-      // path_pt_k = 0 where lo_k == path_pt_{k-1}.  With E_k = (lo_k == cand_{k-1} != 0 ...)
-      // the chain F_k = E_k & ~F_{k-1} is "every other bit of each run of ones".
-      uint32_t cand_v = cand;
-      asm volatile("" : "+v"(cand_v));   // DPP sources must sit in a VGPR
-      const uint32_t cand_prev = dpp_u<0x138>(0u, cand_v);   // wave_shr:1
-      unsigned long long E = __ballot(pa_smp && lo == cand_prev && cand != 0u);
-      uint32_t pt = cand;
-      if (E) {
-        unsigned long long F = E & ~(E << 1);
-        unsigned long long M = E & (E << 1);
-        F |= (F << 2) & M;
-        M &= M << 2;
-        F |= (F << 4) & M;
-        M &= M << 4;
-        F |= (F << 8) & M;
-        M &= M << 8;
-        F |= (F << 16) & M;
-        M &= M << 16;
-        F |= (F << 32) & M;
-        if ((F >> lane) & 1ull) pt = 0;
-      }
-      const bool ok = pa_smp && s_valid[pt];
-      float d = 0.f;
-      if (ok) {
-        const float ddx = s_px[pt] - Tx, ddy = s_py[pt] - Ty;
-        if (p.flags & SD_USE_PATH_YAW) {
-          const double dd = (double)scr_yaw[pa_q] - (double)s_pyaw[pt];
-          double a = fmod(fmod(dd, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
-          if (a > M_PI) a -= 2.0 * M_PI;
-          const float dyaw = (float)a;
-          d = sqrtf(ddx * ddx + ddy * ddy + dyaw * dyaw);
-        } else {
-          d = GENERIC ? sqrtf(ddx * ddx + ddy * ddy) : fast_sqrt(ddx * ddx + ddy * ddy);
-        }
-      }
-      const float summed = wave_sum(d);
-      const float num = (float)__popcll(__ballot(ok));
-      const float c_pa = num > 0.f ? (GENERIC ? summed / num : summed * fast_rcp(num)) : 0.f;
-      if (GENERIC) cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
-      else uni += c_pa * p.pa_weight;
-    }
-
     // ---- PathFollowCritic (path_follow_critic.cpp:56-70) ---------------------
     if (p.flags & SD_PATH_FOLLOW) {
-      const float fdx = scr_x[T - 1] - pf_x, fdy = scr_y[T - 1] - pf_y;
+      const float fdx = ex - pf_x, fdy = ey - pf_y;
       if (GENERIC) {
         const double ddx = (double)fdx, ddy = (double)fdy;
         const double dist = sqrt(ddx * ddx + ddy * ddy);
@@ -660,23 +795,23 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 
     // ---- GoalAngleCritic (goal_angle_critic.cpp:36-50) -----------------------
     if (p.flags & SD_GOAL_ANGLE) {
-      double s = 0.0;
+      double sa = 0.0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if ((uint32_t)(t0 + r) < T) s += fabs(normalize_angle((double)(p.ga_goal_yaw - yaw[r])));
+        if (STEP_OK(r)) sa += fabs(normalize_angle((double)(p.ga_goal_yaw - yaw[r])));
       }
-      const double mean = wave_sum_d(s) / (double)T;
+      const double mean = wave_sum_d(sa) / (double)T;
       if (GENERIC) cost = add_cost_pow(cost, mean * (double)p.ga_weight, p.ga_power);
       else uni += (float)(mean * (double)p.ga_weight);
     }
 
     // ---- PreferForwardCritic (prefer_forward_critic.cpp:33-47) ---------------
     if (p.flags & SD_PREFER_FORWARD) {
-      float s = 0.f;
+      float sb = 0.f;
 #pragma unroll
-      for (int r = 0; r < R; ++r) s += fmaxf(-vx[r], 0.f) * dt;
-      if (GENERIC) cost = add_cost_pow(cost, (double)(wave_sum(s) * p.pfw_weight), p.pfw_power);
-      else lin += s * p.pfw_weight;
+      for (int r = 0; r < R; ++r) sb += fmaxf(-vx[r], 0.f) * dt;
+      if (GENERIC) cost = add_cost_pow(cost, (double)(wave_sum(sb) * p.pfw_weight), p.pfw_power);
+      else lin += sb * p.pfw_weight;
     }
 
     // ---- updateControlSequence gamma terms (optimizer.cpp:365-380) -----------
@@ -700,24 +835,32 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       }
       cost += uni + wave_sum(lin);
     }
-    if (lane == 0) p.costs[b] = cost;
 
-    // ---- online softmax accumulation -----------------------------------------
-    const float m_new = fminf(m_run, cost);
-    // exp(-(c - m)/temperature) as one v_exp_f32: 2^(k2 (c - m)), k2 = -log2(e)/temperature
-    const float f = __builtin_amdgcn_exp2f(p.k2 * (m_run - m_new));   // rescale old sums (<= 1)
-    const float w = __builtin_amdgcn_exp2f(p.k2 * (cost - m_new));
-    s_run = fmaf(s_run, f, w);
+    // ---- park the rollout -----------------------------------------------------
+    {
+      float* cg = cring + (size_t)n_pend * 3 * T;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      Ux[r] = fmaf(Ux[r], f, w * cvx[r]);
-      Uy[r] = fmaf(Uy[r], f, w * cvy[r]);
-      Uz[r] = fmaf(Uz[r], f, w * cwz[r]);
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          cg[t0 + r] = cvx[r];
+          cg[T + t0 + r] = cvy[r];
+          cg[2 * T + t0 + r] = cwz[r];
+        }
+        if (slot[r] >= 0) {
+          const uint32_t q = (n_pend << seg_shift) + (uint32_t)slot[r];
+          pts_x[q] = x[r];
+          pts_y[q] = y[r];
+          if (p.flags & SD_USE_PATH_YAW) pts_yaw[q] = yaw[r];
+        }
+      }
+      if (((uint32_t)lane >> seg_shift) == n_pend) pend_cost = cost;
+      if (++n_pend == GROUP) {
+        flush(n_pend, b);
+        n_pend = 0;
+      }
     }
-    m_run = m_new;
-    __builtin_amdgcn_wave_barrier();
   }
-
+  if (!FURTHEST_ONLY && n_pend) flush(n_pend, b_prev);
   if (want_local_furthest && n_ring)
     S_local = max(S_local, flush_endpoint_ring(ring_x, ring_y, n_ring, s_px, s_py, p.P, lane));
 
@@ -735,7 +878,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     }
     return;
   }
-  const uint32_t TL = 4 + 3 * T;  // == scr_stride is guaranteed >= TL by the host
+  const uint32_t TL = 4 + 3 * T;  // scr_stride >= TL is guaranteed by the host
   float* myp = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
   if (lane == 0) {
     myp[0] = m_run;
@@ -745,7 +888,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    if ((uint32_t)(t0 + r) < T) {
+    if (STEP_OK(r)) {
       myp[4 + t0 + r] = Ux[r];
       myp[4 + T + t0 + r] = Uy[r];
       myp[4 + 2 * T + t0 + r] = Uz[r];
@@ -773,6 +916,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     }
     outp[i] = acc;
   }
+#undef STEP_OK
 }
 
 // ---------------------------------------------------------------------------
@@ -937,14 +1081,14 @@ __global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, 
 // ---------------------------------------------------------------------------
 // launch wrappers (called from smpc_api.cpp through plain C++ linkage)
 // ---------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool FULL>
 static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint32_t grid,
                                 uint32_t block, hipStream_t st)
 {
   switch (R) {
-    case 1: hipLaunchKernelGGL((smpc_pass<1, MODE>), dim3(grid), dim3(block), L.total, st, p, L); break;
-    case 2: hipLaunchKernelGGL((smpc_pass<2, MODE>), dim3(grid), dim3(block), L.total, st, p, L); break;
-    case 4: hipLaunchKernelGGL((smpc_pass<4, MODE>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 1: hipLaunchKernelGGL((smpc_pass<1, MODE, FULL>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 2: hipLaunchKernelGGL((smpc_pass<2, MODE, FULL>), dim3(grid), dim3(block), L.total, st, p, L); break;
+    case 4: hipLaunchKernelGGL((smpc_pass<4, MODE, FULL>), dim3(grid), dim3(block), L.total, st, p, L); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -954,32 +1098,44 @@ static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint3
 hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
                             uint32_t grid, uint32_t block, hipStream_t st)
 {
+  const bool full = p.T == 64u * (uint32_t)R;
   switch (mode) {
-    case 0: return launch_pass_r<0>(R, p, L, grid, block, st);
-    case 1: return launch_pass_r<1>(R, p, L, grid, block, st);
-    default: return launch_pass_r<2>(R, p, L, grid, block, st);
+    case 0: return full ? launch_pass_r<0, true>(R, p, L, grid, block, st)
+                        : launch_pass_r<0, false>(R, p, L, grid, block, st);
+    case 1: return full ? launch_pass_r<1, true>(R, p, L, grid, block, st)
+                        : launch_pass_r<1, false>(R, p, L, grid, block, st);
+    default: return full ? launch_pass_r<2, true>(R, p, L, grid, block, st)
+                         : launch_pass_r<2, false>(R, p, L, grid, block, st);
   }
 }
 
-hipError_t smpc_pass_occupancy(int R, int mode, uint32_t block, uint32_t lds_bytes, int* blocks_per_cu)
+template <typename F>
+static void for_each_pass_kernel(F&& f)
 {
-  const void* f = nullptr;
-#define PICK(RR, MM) if (R == RR && mode == MM) f = reinterpret_cast<const void*>(&smpc_pass<RR, MM>);
-  PICK(1, 0) PICK(2, 0) PICK(4, 0) PICK(1, 1) PICK(2, 1) PICK(4, 1) PICK(1, 2) PICK(2, 2) PICK(4, 2)
-#undef PICK
-  if (!f) return hipErrorInvalidValue;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, (int)block, lds_bytes);
+#define EACH(RR, MM) f(reinterpret_cast<const void*>(&smpc_pass<RR, MM, true>), RR, MM, true); \
+                     f(reinterpret_cast<const void*>(&smpc_pass<RR, MM, false>), RR, MM, false);
+  EACH(1, 0) EACH(2, 0) EACH(4, 0) EACH(1, 1) EACH(2, 1) EACH(4, 1) EACH(1, 2) EACH(2, 2) EACH(4, 2)
+#undef EACH
+}
+
+hipError_t smpc_pass_occupancy(int R, int mode, bool full, uint32_t block, uint32_t lds_bytes,
+                               int* blocks_per_cu)
+{
+  const void* fn = nullptr;
+  for_each_pass_kernel([&](const void* f, int r, int m, bool fl) {
+    if (r == R && m == mode && fl == full) fn = f;
+  });
+  if (!fn) return hipErrorInvalidValue;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, (int)block, lds_bytes);
 }
 
 hipError_t smpc_set_pass_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-#define SET(R, FO)                                                                              \
-  if (e == hipSuccess)                                                                          \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass<R, FO>),                   \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  SET(1, 0) SET(2, 0) SET(4, 0) SET(1, 1) SET(2, 1) SET(4, 1) SET(1, 2) SET(2, 2) SET(4, 2)
-#undef SET
+  for_each_pass_kernel([&](const void* f, int, int, bool) {
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  });
   return e;
 }
 
