@@ -160,8 +160,9 @@ def main():
     ap.add_argument("--rollouts-per-gpu", type=int, default=SHARD_ROLLOUTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
-    ap.add_argument("--speculate", action="store_true",
-                    help="skip the furthest-point exchange by speculating on the previous tick's value")
+    ap.add_argument("--no-speculate", action="store_true",
+                    help="N > 1: always exchange the furthest point first (two collectives per tick) "
+                         "instead of speculating on the previous tick's value and re-scoring on a miss")
     args = ap.parse_args()
 
     import torch
@@ -174,17 +175,23 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SMPC_BENCH_FORCE_DIST=1 drives the sharded path (RCCL collectives included) with a
+    # single rank: a rehearsal of the N > 1 code path on a one-GPU box
+    force_dist = os.environ.get("SMPC_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B, T, MAP = args.rollouts_per_gpu, HORIZON, 200
     g, scn, cfg = make_ctx(B, T, MAP, shard_offset=rank * B, global_batch=world * B)
     P = len(scn.tick.path_x)
 
-    if world > 1:
+    if world > 1 or force_dist:
         from mpcholonavigation_amd.sharded import HipShard, ShardedOptimizer
-        so = ShardedOptimizer(HipShard(g), speculate=args.speculate)
+        so = ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
         step_fn = so.optimize
 
         def barrier():
@@ -197,7 +204,7 @@ def main():
 
     el, pass_ms, dev_ms, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
                                                  torch.cuda.synchronize, barrier)
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([el, pass_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, pass_ms = float(t[0]), float(t[1])
@@ -225,8 +232,8 @@ def main():
                 "rollouts_per_gpu": B, "horizon": T, "costmap": "200x200", "path_points": P,
                 "critics": ["Obstacles", "PathAlign", "PathFollow", "GoalAngle", "PreferForward"],
                 "exchange": ("none" if world == 1 else
-                             ("all_gather(tuple) [speculative furthest]" if args.speculate else
-                              "all_reduce(max furthest) + all_gather(tuple)")) ,
+                             ("all_reduce(max furthest) + all_gather(tuple)" if args.no_speculate else
+                              "all_gather(tuple); furthest point speculated, re-scored on a miss")),
                 "furthest_reached_path_point": int(out.furthest_reached_path_point),
                 "scoring_passes_per_tick": passes,
             },
@@ -251,7 +258,7 @@ def main():
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     g.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

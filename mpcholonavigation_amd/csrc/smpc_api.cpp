@@ -28,11 +28,12 @@ hipError_t smpc_pass_occupancy(int R, int mode, bool full, uint32_t block, uint3
                                int* blocks_per_cu);
 hipError_t smpc_set_pass_lds_limit(int bytes);
 hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
-                              float neg_inv_temp, float* tuple, hipStream_t st);
+                              float neg_inv_temp, float* tuple, const SmpcFinal& fin,
+                              hipStream_t st);
 hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, float neg_inv_temp,
                                float vx_max, float vx_min, float vy_max, float wz_max,
                                float* u_out, float* result, const float* furthest_used,
-                               hipStream_t st);
+                               float* host_out, hipStream_t st);
 hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
 
@@ -103,6 +104,10 @@ struct smpc_ctx {
   uint8_t* d_map = nullptr;
   size_t d_map_bytes = 0;
   // per-tick block
+  SmpcLut* d_lut = nullptr;
+  SmpcLut* h_lut = nullptr;     // pinned
+  uint64_t lut_key = 0, map_version = 1, critics_version = 1;
+  bool lut_valid = false;
   uint8_t* d_tick = nullptr;
   uint8_t* h_tick = nullptr;  // pinned
   size_t tick_cap = 0;
@@ -110,7 +115,8 @@ struct smpc_ctx {
   float* d_partials = nullptr;
   float* d_tuple = nullptr;
   float* d_out = nullptr;       // [3T u][8 result]
-  float* h_out = nullptr;       // pinned mirror
+  float* h_out = nullptr;       // pinned, device-mapped: kernels write the result here
+  float* h_out_dev = nullptr;   // its device-side address
   float* d_furthest = nullptr;  // one float (atomicMax on its bits)
   // launch geometry
   int R = 1;
@@ -164,6 +170,8 @@ void free_ctx(smpc_ctx* c)
     if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
   if (c->d_tick) (void)hipFree(c->d_tick);
+  if (c->d_lut) (void)hipFree(c->d_lut);
+  if (c->h_lut) (void)hipHostFree(c->h_lut);
   if (c->h_tick) (void)hipHostFree(c->h_tick);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -175,7 +183,7 @@ void free_ctx(smpc_ctx* c)
 
 // tick block layout (offsets in bytes), sized for the ctx's T and SMPC_MAX_PATH
 struct TickLayout {
-  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, lut, total;
+  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, total;
 };
 TickLayout tick_layout(uint32_t T, uint32_t P)
 {
@@ -189,7 +197,6 @@ TickLayout tick_layout(uint32_t T, uint32_t P)
   l.pf_idx = o; o += align_up(P * 4, 16);
   l.pvalid = o; o += align_up(P, 16);
   l.pa_active = o; o += align_up(P, 16);
-  l.lut = o; o += 256 * sizeof(SmpcLut);
   l.total = o;
   return l;
 }
@@ -434,13 +441,17 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     memset(pf_idx, 0, std::max(P, 1u) * 4);
   }
 
-  // ---- Obstacles LUT -------------------------------------------------------------
-  SmpcLut* lut = reinterpret_cast<SmpcLut*>(h + tl.lut);
+  // ---- Obstacles LUT: rebuilt and uploaded only when its inputs changed -----------
   if (gates & SD_OBSTACLES) {
     const bool near_goal = within_tol(cr.obstacles.near_goal_distance, rx, ry, gx, gy);  // :124-127
-    build_lut(c, near_goal, lut);
-  } else {
-    memset(lut, 0, 256 * sizeof(SmpcLut));
+    const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 1) ^ (near_goal ? 1u : 0u);
+    if (!c->lut_valid || key != c->lut_key) {
+      build_lut(c, near_goal, c->h_lut);
+      HIPCK(c, hipMemcpyAsync(c->d_lut, c->h_lut, 256 * sizeof(SmpcLut), hipMemcpyHostToDevice,
+                              c->stream));
+      c->lut_key = key;
+      c->lut_valid = true;
+    }
   }
 
   HIPCK(c, hipEventRecord(c->ev0, c->stream));
@@ -471,7 +482,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     const double eps = 2.0 * (e_o * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
     d.cell_eps = static_cast<float>(std::min(eps, 0.5));
   }
-  d.lut = reinterpret_cast<const SmpcLut*>(c->d_tick + tl.lut);
+  d.lut = c->d_lut;
   d.px = reinterpret_cast<const float*>(c->d_tick + tl.px);
   d.py = reinterpret_cast<const float*>(c->d_tick + tl.py);
   d.pyaw = reinterpret_cast<const float*>(c->d_tick + tl.pyaw);
@@ -555,8 +566,12 @@ int launch_furthest(smpc_ctx* c, float* d_furthest)
 }
 
 // one scoring pass + block reduction -> tuple
+// finish_furthest: when `finish`, the reduction also produces the new control sequence
+// (single-GPU tick) and reports *finish_furthest (or the pass's own value) as the furthest
+// point the critics used
 int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
-                 uint32_t furthest_hint, float* d_tuple)
+                 uint32_t furthest_hint, float* d_tuple, bool finish = false,
+                 const float* finish_furthest = nullptr)
 {
   SmpcDev d = c->dev;
   d.flags = flags;
@@ -572,7 +587,11 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
     HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
     c->evp_used += 2;
   }
-  HIPCK(c, smpc_launch_reduce(c->d_partials, c->grid, d.T, d.neg_inv_temp, d_tuple, c->stream));
+  SmpcFinal fin{};
+  fin.enabled = finish ? 1 : 0;
+  fin.vx_max = c->c_vx_max; fin.vx_min = c->c_vx_min; fin.vy_max = c->c_vy; fin.wz_max = c->c_wz;
+  fin.u_dev = c->d_out; fin.u_host = c->h_out_dev; fin.furthest_used = finish_furthest;
+  HIPCK(c, smpc_launch_reduce(c->d_partials, c->grid, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
   c->passes++;
   return SMPC_OK;
 }
@@ -582,15 +601,13 @@ int launch_combine(smpc_ctx* c, const float* d_tuples, uint32_t n, const float* 
   const uint32_t T = c->cfg.time_steps;
   HIPCK(c, smpc_launch_combine(d_tuples, n, T, c->dev.neg_inv_temp, c->c_vx_max, c->c_vx_min,
                                c->c_vy, c->c_wz, c->d_out, c->d_out + 3 * T, d_furthest_used,
-                               c->stream));
+                               c->h_out_dev, c->stream));
   return SMPC_OK;
 }
 
 int fetch_out(smpc_ctx* c)
 {
-  const uint32_t T = c->cfg.time_steps;
-  HIPCK(c, hipMemcpyAsync(c->h_out, c->d_out, (3 * T + 8) * sizeof(float), hipMemcpyDeviceToHost,
-                          c->stream));
+  // the finishing kernel wrote u and the result into host-mapped memory: just wait
   HIPCK(c, hipStreamSynchronize(c->stream));
   return SMPC_OK;
 }
@@ -740,11 +757,15 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   c->tick_cap = tick_layout(T, SMPC_MAX_PATH).total;
   CK(hipMalloc(&c->d_tick, c->tick_cap));
   CK(hipHostMalloc(&c->h_tick, c->tick_cap, hipHostMallocDefault));
+  CK(hipMalloc(&c->d_lut, 256 * sizeof(SmpcLut)));
+  CK(hipMemset(c->d_lut, 0, 256 * sizeof(SmpcLut)));
+  CK(hipHostMalloc(&c->h_lut, 256 * sizeof(SmpcLut), hipHostMallocDefault));
   const size_t TL = 4 + 3 * static_cast<size_t>(T);
   CK(hipMalloc(&c->d_partials, kMaxGrid * TL * sizeof(float)));
   CK(hipMalloc(&c->d_tuple, TL * sizeof(float)));
   CK(hipMalloc(&c->d_out, (3 * T + 8) * sizeof(float)));
-  CK(hipHostMalloc(&c->h_out, (3 * T + 8) * sizeof(float), hipHostMallocDefault));
+  CK(hipHostMalloc(&c->h_out, (3 * T + 8) * sizeof(float), hipHostMallocMapped));
+  CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_out_dev), c->h_out, 0));
   CK(hipMalloc(&c->d_furthest, 16));
   CK(hipMemset(c->d_furthest, 0, 16));
   CK(smpc_set_pass_lds_limit(static_cast<int>(kLdsPerCu)));
@@ -788,6 +809,7 @@ int smpc_set_critics(smpc_ctx* c, const smpc_critic_params* p)
   if (p->obstacles.enabled && p->obstacles.consider_footprint)
     return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
   c->critics = *p;
+  c->critics_version++;
   return SMPC_OK;
 }
 
@@ -814,6 +836,7 @@ int smpc_set_costmap(smpc_ctx* c, const uint8_t* cells, uint32_t width, uint32_t
   m.cost_scaling_factor = cost_scaling_factor;
   m.inflation_radius = inflation_radius;
   m.set = true;
+  c->map_version++;
   HIPCK(c, hipMemcpyAsync(c->d_map, m.cells.data(), bytes, hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
   return SMPC_OK;
@@ -910,9 +933,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
         dF = c->d_furthest;
       }
     }
-    rc = launch_score(c, flags, u_dev, dF, hintS, c->d_tuple);
-    if (rc != SMPC_OK) return rc;
-    rc = launch_combine(c, c->d_tuple, 1, dF);
+    rc = launch_score(c, flags, u_dev, dF, hintS, c->d_tuple, true, dF);
     if (rc != SMPC_OK) return rc;
     HIPCK(c, hipEventRecord(c->ev1, c->stream));
     fetched = false;
@@ -935,9 +956,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
       if (S_true != hintS) {
         c->spec_misses++;
         flags &= ~SD_LOCAL_FURTHEST;
-        rc = launch_score(c, flags, u_dev, nullptr, S_host, c->d_tuple);
-        if (rc != SMPC_OK) return rc;
-        rc = launch_combine(c, c->d_tuple, 1, nullptr);
+        rc = launch_score(c, flags, u_dev, nullptr, S_host, c->d_tuple, true, nullptr);
         if (rc != SMPC_OK) return rc;
         HIPCK(c, hipEventRecord(c->ev1, c->stream));
         rc = fetch_out(c);
@@ -952,9 +971,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
       fail_sticky = true;
       const uint32_t only = (c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN)) |
         (it > 0 ? SD_ACCUMULATE : 0u);
-      rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple);
-      if (rc != SMPC_OK) return rc;
-      rc = launch_combine(c, c->d_tuple, 1, nullptr);
+      rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple, true, nullptr);
       if (rc != SMPC_OK) return rc;
       HIPCK(c, hipEventRecord(c->ev1, c->stream));
       fetched = false;

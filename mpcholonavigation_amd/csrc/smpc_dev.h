@@ -86,6 +86,15 @@ struct SmpcDev {
   uint32_t* furthest_out;  // atomicMax target of the furthest-only pass (float bits)
 };
 
+// optional finishing step of smpc_reduce_partials (single tuple -> new control sequence)
+struct SmpcFinal {
+  int enabled;
+  float vx_max, vx_min, vy_max, wz_max;   // current constraints
+  float* u_dev;                            // [3T + 8] device copy (next iteration reads u here)
+  float* u_host;                           // [3T + 8] host-mapped copy (no D2H memcpy)
+  const float* furthest_used;              // device float or null
+};
+
 // LDS carve-up, computed once on the host and passed to the kernel.
 struct SmpcLds {
   uint32_t off_lut, off_px, off_py, off_pyaw, off_D, off_valid, off_scr;

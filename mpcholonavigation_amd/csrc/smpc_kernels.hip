@@ -924,10 +924,14 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 // {min, sum w, furthest, non-colliding, U[3T]}.  Block j owns 32 tuple columns;
 // its 1024 threads are 32 columns x 32 row slices (coalesced 128-B row pieces).
 // ---------------------------------------------------------------------------
+// With fin.enabled (single-GPU tick, one tuple) every block also finishes its columns:
+// divide by sum w, clip, write the new control sequence to device AND host-mapped memory
+// (optimizer.cpp:382-393,237-249) — the separate combine launch and the D2H copy go away.
 __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __restrict__ partials,
                                                             uint32_t nblk, uint32_t T,
                                                             float neg_inv_temp,
-                                                            float* __restrict__ tuple)
+                                                            float* __restrict__ tuple,
+                                                            const SmpcFinal fin)
 {
   __shared__ float s_red[16], s_red2[16], s_red3[16];
   __shared__ float s_sc[2048];
@@ -971,7 +975,19 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
     for (uint32_t g = sl; g < nblk; g += 32) acc += s_sc[g] * partials[(size_t)g * TL + col];
   }
   s_acc[sl][tid & 31] = acc;
+  // sum of weights (tuple column 1), needed by every block when it finishes its columns
+  float sw = 0.f;
+  if (fin.enabled) {
+    float a = 0.f;
+    for (uint32_t g = tid; g < nblk; g += blockDim.x) a += s_sc[g] * partials[(size_t)g * TL + 1];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+    __syncthreads();   // s_red* free again
+    if (lane == 0) s_red[wave] = a;
+  }
   __syncthreads();
+  if (fin.enabled) {
+    for (int w = 0; w < nwave; ++w) sw += s_red[w];
+  }
   if (sl == 0 && col < TL) {
     float r = 0.f;
 #pragma unroll
@@ -980,6 +996,25 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
     if (col == 2) r = fu;
     if (col == 3) r = nc;
     tuple[col] = r;
+    if (fin.enabled) {
+      if (col >= 4) {
+        const uint32_t i = col - 4;
+        float v = r / sw;
+        // applyControlSequenceConstraints (optimizer.cpp:237-249)
+        if (i < T) v = fminf(fmaxf(v, fin.vx_min), fin.vx_max);
+        else if (i < 2 * T) v = fminf(fmaxf(v, -fin.vy_max), fin.vy_max);
+        else v = fminf(fmaxf(v, -fin.wz_max), fin.wz_max);
+        fin.u_dev[i] = v;
+        fin.u_host[i] = v;
+      } else if (col == 0) {
+        const float used = fin.furthest_used ? *fin.furthest_used : fu;
+        const float res[5] = {m, sw, fu, nc, used};
+        for (int k = 0; k < 5; ++k) {
+          fin.u_dev[3 * T + k] = res[k];
+          fin.u_host[3 * T + k] = res[k];
+        }
+      }
+    }
   }
 }
 
@@ -994,7 +1029,8 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
                                                           float vx_min, float vy_max,
                                                           float wz_max, float* __restrict__ u_out,
                                                           float* __restrict__ result,
-                                                          const float* __restrict__ furthest_used)
+                                                          const float* __restrict__ furthest_used,
+                                                          float* __restrict__ host_out)
 {
   const uint32_t TL = 4 + 3 * T;
   float m = 3.0e38f, fu = 0.f, nc = 0.f;
@@ -1016,14 +1052,15 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
     else if (i < 2 * T) v = fminf(fmaxf(v, -vy_max), vy_max);
     else v = fminf(fmaxf(v, -wz_max), wz_max);
     u_out[i] = v;
+    if (host_out) host_out[i] = v;
   }
   if (threadIdx.x == 0) {
-    result[0] = m;
-    result[1] = sw;
-    result[2] = fu;
-    result[3] = nc;
-    // the furthest point the critics consumed (cached across iterations)
-    result[4] = furthest_used ? *furthest_used : fu;
+    // [4]: the furthest point the critics consumed (cached across iterations)
+    const float res[5] = {m, sw, fu, nc, furthest_used ? *furthest_used : fu};
+    for (int k = 0; k < 5; ++k) {
+      result[k] = res[k];
+      if (host_out) host_out[3 * T + k] = res[k];
+    }
   }
 }
 
@@ -1140,21 +1177,22 @@ hipError_t smpc_set_pass_lds_limit(int bytes)
 }
 
 hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
-                              float neg_inv_temp, float* tuple, hipStream_t st)
+                              float neg_inv_temp, float* tuple, const SmpcFinal& fin,
+                              hipStream_t st)
 {
   const uint32_t TL = 4 + 3 * T;
   hipLaunchKernelGGL(smpc_reduce_partials, dim3((TL + 31) / 32), dim3(1024), 0, st, partials, nblk,
-                     T, neg_inv_temp, tuple);
+                     T, neg_inv_temp, tuple, fin);
   return hipGetLastError();
 }
 
 hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, float neg_inv_temp,
                                float vx_max, float vx_min, float vy_max, float wz_max,
                                float* u_out, float* result, const float* furthest_used,
-                               hipStream_t st)
+                               float* host_out, hipStream_t st)
 {
   hipLaunchKernelGGL(smpc_combine_tuples, dim3(1), dim3(256), 0, st, tuples, G, T, neg_inv_temp,
-                     vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used);
+                     vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used, host_out);
   return hipGetLastError();
 }
 

@@ -68,10 +68,10 @@ class ShardedOptimizer:
         self.rescored = 0         # speculation misses so far
 
     def _gather(self):
-        if self.G == 1:
-            self.t_all.copy_(self.t_tuple)
-        else:
+        if dist.is_initialized():
             dist.all_gather_into_tensor(self.t_all, self.t_tuple, group=self.group)
+        else:
+            self.t_all.copy_(self.t_tuple)
 
     def optimize(self, tick, u):
         """One tick: returns (u_new [3,T], SmpcTickOut) — identical on every rank."""
@@ -90,7 +90,7 @@ class ShardedOptimizer:
                 u_new, out = b.combine(self.t_all, self.G)
         else:
             b.furthest(self.t_furthest)
-            if self.G > 1:
+            if dist.is_initialized():
                 dist.all_reduce(self.t_furthest, op=dist.ReduceOp.MAX, group=self.group)
             b.score(self.t_furthest, 0, self.t_tuple)
             self._gather()
