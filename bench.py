@@ -40,6 +40,23 @@ def algorithmic_bytes(B, T, W, H, P):
     return B * (12 * T + 8) + min(W * H, B * T) + 12 * P + 24 * T
 
 
+def measured_traffic(B, T, costmap):
+    """HBM bytes per launch of the scoring pass from the committed rocprofv3 PMC passes
+    (profiles/<round>/traffic.json: FETCH_SIZE with the gfx950 x2 correction calibrated on the
+    furthest-only pass + WRITE_SIZE) when one exists for exactly this workload, else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            w = t["workload"]
+            if (w["rollouts"], w["horizon"], w["costmap"]) == (B, T, costmap):
+                return float(t["traffic_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def shift(u):
     """Optimizer::shiftControlSequence (src/optimizer.cpp:206-225)."""
     return np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
@@ -212,6 +229,7 @@ def main():
     if rank == 0:
         by = algorithmic_bytes(B, T, MAP, MAP, P)
         achieved = by / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(B, T, f"{MAP}x{MAP}")
         line = {
             "metric": "rollouts/sec per computeVelocityCommands() tick",
             "value": world * B * cfg.iteration_count * args.steps / el,
@@ -240,7 +258,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "smpc_pass<1,0>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": by,
                 "avg_launch_ms": pass_ms,
                 "device_ms_per_tick": dev_ms,

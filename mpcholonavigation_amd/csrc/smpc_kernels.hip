@@ -136,6 +136,16 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Keep a wave-uniform loop constant in a VGPR: the scoring loop has far more uniform
+// values than the 102 SGPRs hold, and what the compiler spills from SGPRs comes back as one
+// v_readlane per use.  VALU sources are free to be VGPRs.
+template <typename V>
+__device__ __forceinline__ V in_vgpr(V x)
+{
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // 1-ulp hardware sqrt / reciprocal (MODE 0: the terms they feed are continuous in
 // their inputs, so a last-bit difference moves a cost by ~1e-7 relative)
 __device__ __forceinline__ float fast_sqrt(float v) {return __builtin_amdgcn_sqrtf(v);}
@@ -215,13 +225,16 @@ __device__ __forceinline__ bool cell_index_exact(double w, double o, double res,
 // lies within that bound of a cell edge can truncate differently; those lanes
 // (a fraction ~4*cell_eps) redo both axes in double with the true division, so
 // every lookup reads the cell the reference reads.
-__device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const uint8_t* s_map, float x,
-                                            float y)
+struct CellConsts {   // loop constants of cost_at, held in VGPRs
+  float oxf, oyf, rinvf, lo, hi;
+};
+__device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const CellConsts& k,
+                                            const uint8_t* s_map, float x, float y)
 {
-  const float qx = (x - p.oxf) * p.rinvf, qy = (y - p.oyf) * p.rinvf;
+  const float qx = (x - k.oxf) * k.rinvf, qy = (y - k.oyf) * k.rinvf;
   const float fx = floorf(qx), fy = floorf(qy);
   const float rx = qx - fx, ry = qy - fy;
-  const float lo = p.cell_eps, hi = 1.0f - p.cell_eps;
+  const float lo = k.lo, hi = k.hi;
   uint32_t mx = (uint32_t)(int)fx, my = (uint32_t)(int)fy;   // negative / huge -> >= W
   bool on = mx < p.W && my < p.H;
   if (__builtin_expect(!(rx >= lo && rx <= hi && ry >= lo && ry <= hi), 0)) {
@@ -330,7 +343,7 @@ __device__ __forceinline__ float seg_scan_add(float v, uint32_t seg_shift)
 // then the weighted controls of the group are accumulated.
 // ---------------------------------------------------------------------------
 template <int R, int MODE, bool FULL>
-__global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pass(const SmpcDev p, const SmpcLds L)
+__global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pass(const SmpcDev p, const SmpcLds L)
 {
   constexpr bool FURTHEST_ONLY = MODE == 1;
   constexpr bool GENERIC = MODE == 2;
@@ -345,7 +358,9 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
-  const int wave = tid >> 6;
+  // wave-uniform by construction: tell the compiler, so that the rollout index, the row
+  // addresses and the loop control live on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwave = blockDim.x >> 6;
   float* scr = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
   float* pts_x = scr + L.scr_pts;        // [64] PathAlign sample points, slot = g*SEG + s
@@ -401,7 +416,14 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     uvy[r] = a ? p.u[T + t0 + r] : 0.f;
     uwz[r] = a ? p.u[2 * T + t0 + r] : 0.f;
   }
-  const float dt = p.dt;
+  const float dt = in_vgpr(p.dt);
+  const float yaw0_v = in_vgpr(p.yaw0);
+  const double x0_v = in_vgpr(p.x0), y0_v = in_vgpr(p.y0);
+  const CellConsts cellk = {in_vgpr(p.oxf), in_vgpr(p.oyf), in_vgpr(p.rinvf), in_vgpr(p.cell_eps),
+                            in_vgpr(1.0f - p.cell_eps)};
+  const float obs_cw = in_vgpr(p.obs_critical_w), obs_rt = in_vgpr(p.obs_rep_over_T);
+  const float pfw_w = in_vgpr(p.pfw_weight), pf_w = in_vgpr(p.pf_weight), pa_w = in_vgpr(p.pa_weight);
+  const float k2_v = in_vgpr(p.k2);
   // {initial value in lane 0, 0 elsewhere}: addends of the fused shift (dpp_shr1_add)
   const float first_vx = lane == 0 ? p.svx : 0.f, first_vy = lane == 0 ? p.svy : 0.f;
   const float first_wz = lane == 0 ? p.swz : 0.f;
@@ -433,6 +455,9 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     bs_iters = S > 1 ? 32u - (uint32_t)__builtin_clz(S - 1) : 0u;  // ceil(log2 S)
     if (pa_on && S > 1 && s_D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / s_D[S - 1];
   }
+  pf_x = in_vgpr(pf_x);
+  pf_y = in_vgpr(pf_y);
+  pa_inv_spacing = in_vgpr(pa_inv_spacing);
   const bool want_local_furthest =
     FURTHEST_ONLY || ((p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST));
   // group geometry: GROUP rollouts parked per flush, SEG lanes (sample slots) per rollout
@@ -561,7 +586,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       const float num = (float)__popcll(okm & segm);
       const float c_pa = num > 0.f ? (GENERIC ? summed / num : summed * fast_rcp(num)) : 0.f;
       if (GENERIC) cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
-      else cost += c_pa * p.pa_weight;
+      else cost += c_pa * pa_w;
     }
     // costs_ [B]: one lane per parked rollout
     if (rowon && s == 0) p.costs[b_last - (n - 1 - g) * nW] = cost;
@@ -570,8 +595,8 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
     const float cmin = wave_min_f(rowon ? cost : 3.0e38f);
     const float m_new = fminf(m_run, cmin);
     // exp(-(c - m)/temperature) as one v_exp_f32: 2^(k2 (c - m)), k2 = -log2(e)/temperature
-    const float f = __builtin_amdgcn_exp2f(p.k2 * (m_run - m_new));   // rescale old sums (<= 1)
-    const float w = rowon ? __builtin_amdgcn_exp2f(p.k2 * (cost - m_new)) : 0.f;
+    const float f = __builtin_amdgcn_exp2f(k2_v * (m_run - m_new));   // rescale old sums (<= 1)
+    const float w = rowon ? __builtin_amdgcn_exp2f(k2_v * (cost - m_new)) : 0.f;
     s_run = fmaf(s_run, f, wave_sum(s == 0 ? w : 0.f));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -659,10 +684,10 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       }
       const float incl = wave_scan_add(acc);
       if (R == 1) {
-        yaw[0] = incl + p.yaw0;   // one step per lane: the inclusive scan is the cumsum
+        yaw[0] = incl + yaw0_v;   // one step per lane: the inclusive scan is the cumsum
       } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) yaw[r] = dpp_shr1_add(incl, yaw[r]) + p.yaw0;
+        for (int r = 0; r < R; ++r) yaw[r] = dpp_shr1_add(incl, yaw[r]) + yaw0_v;
       }
     }
     float x[R], y[R];
@@ -688,13 +713,13 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
       float sx = ax, sy = ay;
       wave_scan_add2(sx, sy);
       if (R == 1) {
-        x[0] = (float)(p.x0 + (double)sx);
-        y[0] = (float)(p.y0 + (double)sy);
+        x[0] = (float)(x0_v + (double)sx);
+        y[0] = (float)(y0_v + (double)sy);
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          x[r] = (float)(p.x0 + (double)dpp_shr1_add(sx, x[r]));
-          y[r] = (float)(p.y0 + (double)dpp_shr1_add(sy, y[r]));
+          x[r] = (float)(x0_v + (double)dpp_shr1_add(sx, x[r]));
+          y[r] = (float)(y0_v + (double)dpp_shr1_add(sy, y[r]));
         }
       }
     }
@@ -752,7 +777,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
         if (STEP_OK(r) && first_r == R) {
           // point 0 is the same for every rollout (v[:,0] is the measured speed): its
           // cell was looked up once on the host with the same arithmetic
-          const uint32_t c = (t0 + r == 0) ? p.cost_t0 : cost_at(p, s_map, x[r], y[r]);
+          const uint32_t c = (t0 + r == 0) ? p.cost_t0 : cost_at(p, cellk, s_map, x[r], y[r]);
           const SmpcLut e = s_lut[c];
           if (e.crit < 0.f) {   // inCollision
             first_r = r;
@@ -776,7 +801,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
         const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
         cost = add_cost_pow(cost, (double)v, p.obs_power);
       } else {
-        lin = (collided ? 0.f : p.obs_critical_w * crit) + p.obs_rep_over_T * rep;
+        lin = (collided ? 0.f : obs_cw * crit) + obs_rt * rep;
         uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
       }
     }
@@ -789,7 +814,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
         const double dist = sqrt(ddx * ddx + ddy * ddy);
         cost = add_cost_pow(cost, (double)p.pf_weight * dist, p.pf_power);
       } else {
-        uni += p.pf_weight * fast_sqrt(fdx * fdx + fdy * fdy);
+        uni += pf_w * fast_sqrt(fdx * fdx + fdy * fdy);
       }
     }
 
@@ -811,7 +836,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 6 : (R == 2 ? 4 : 3))) smpc_pas
 #pragma unroll
       for (int r = 0; r < R; ++r) sb += fmaxf(-vx[r], 0.f) * dt;
       if (GENERIC) cost = add_cost_pow(cost, (double)(wave_sum(sb) * p.pfw_weight), p.pfw_power);
-      else lin += sb * p.pfw_weight;
+      else lin += sb * pfw_w;
     }
 
     // ---- updateControlSequence gamma terms (optimizer.cpp:365-380) -----------
