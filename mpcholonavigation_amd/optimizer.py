@@ -9,6 +9,7 @@ device half.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -30,6 +31,14 @@ def load_library():
     Raises if the library was not built (no silent fallback)."""
     global _lib
     if _lib is None:
+        # libsmpc and PyTorch-ROCm both link libamdhip64.so.7 and the first copy loaded serves
+        # the whole process.  torch only finds its GPUs with its own bundled runtime, while
+        # libsmpc runs on either, so when torch is installed it goes first.
+        if "torch" not in sys.modules and not os.environ.get("SMPC_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C mpcholonavigation_amd/csrc` "

@@ -1,0 +1,204 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (where the
+oracle is too slow to be the checker), plus shape edge cases and the multi-query
+configuration (replicas only)."""
+import numpy as np
+import pytest
+
+from mpcholonavigation_amd import _abi as A
+from mpcholonavigation_amd.synthetic import make_noise, make_scenario
+from mpcholonavigation_amd.tick import Tick, default_config, default_critics
+from tests.helpers import assert_parity, configure, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FULL = [(65536, 64, 200),      # configs[1]
+        (262144, 128, 2000),   # configs[2]
+        (262144, 64, 200)]     # configs[3] per-GPU shard
+
+
+def _ctx(B, T, map_size, noise=None, seed=None, **cfg_kw):
+    from mpcholonavigation_amd.optimizer import Smpc
+    cfg = default_config(batch_size=B, time_steps=T, **cfg_kw)
+    scn = make_scenario(T, map_size=map_size)
+    g = Smpc(cfg)
+    configure(g, scn, noise=noise)
+    if seed is not None:
+        g.seed(seed)
+    return g, scn
+
+
+@pytest.mark.parametrize("B,T,M", FULL)
+def test_full_size_determinism_and_permutation_invariance(B, T, M):
+    """Same inputs -> bit-identical control sequence; permuting the rollouts (rows of the
+    noise tensors) changes only the float summation order."""
+    g, scn = _ctx(B, T, M, seed=11)
+    u1, o1 = g.optimize(scn.tick, scn.u0)
+    u2, o2 = g.optimize(scn.tick, scn.u0)
+    assert np.array_equal(u1, u2) and o1.min_cost == o2.min_cost
+    nvx, nvy, nwz = g.get_noise()
+    perm = np.random.default_rng(0).permutation(B)
+    g.set_noise(nvx[perm], nvy[perm], nwz[perm])
+    u3, o3 = g.optimize(scn.tick, scn.u0)
+    assert o3.min_cost == o1.min_cost and o3.non_colliding == o1.non_colliding
+    assert o3.furthest_reached_path_point == o1.furthest_reached_path_point
+    assert rel_err(u3, u1) < 5e-6
+    c1 = np.sort(g.get_costs())
+    g.set_noise(nvx, nvy, nwz)
+    g.optimize(scn.tick, scn.u0)
+    assert np.array_equal(np.sort(g.get_costs()), c1)      # the multiset of costs is the same
+
+
+@pytest.mark.parametrize("B,T,M", FULL)
+def test_full_size_zero_noise_is_a_fixed_point(B, T, M):
+    """With zero noise every rollout is the same: equal weights, so the update returns the
+    (clipped) input sequence and every cost is identical."""
+    z = np.zeros((B, T), np.float32)
+    g, scn = _ctx(B, T, M, noise=(z, z, z))
+    u0 = scn.u0.copy()
+    u0[1] = 0.02
+    u0[2] = np.linspace(-0.1, 0.1, T)
+    u, out = g.optimize(scn.tick, u0)
+    assert np.max(np.abs(u - u0)) < 1e-6
+    c = g.get_costs()
+    assert np.all(c == c[0])
+    assert abs(out.sum_w - B) < 1e-3 * B
+
+
+@pytest.mark.parametrize("B,T,M", FULL)
+def test_full_size_shards_sum_to_the_whole(B, T, M):
+    """Two half-batch contexts (device RNG slices of the same stream) combine to the
+    whole-batch tick: the data path of the 2-GPU run on one GPU."""
+    import torch
+    g, scn = _ctx(B, T, M, seed=5)
+    u_w, out_w = g.optimize(scn.tick, scn.u0)
+    halves = []
+    for k in range(2):
+        h, _ = _ctx(B // 2, T, M, seed=5, shard_offset=k * (B // 2), global_batch_size=B)
+        halves.append(h)
+    dev = torch.device("cuda", 0)
+    L = halves[0].tuple_len
+    t_all = torch.zeros(2 * L, dtype=torch.float32, device=dev)
+    S = int(out_w.furthest_reached_path_point)
+    for k, h in enumerate(halves):
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        h.shard_begin(scn.tick, scn.u0)
+        h.shard_score(0, S, t_all[k * L:].data_ptr())
+    u_s, out_s = halves[0].shard_combine(t_all.data_ptr(), 2)
+    assert out_s.furthest_reached_path_point == S
+    assert out_s.non_colliding == out_w.non_colliding
+    assert abs(out_s.min_cost - out_w.min_cost) <= 1e-6 * max(1.0, abs(out_w.min_cost))
+    assert rel_err(u_s, u_w) < 5e-6
+
+
+def test_multi_query_replicas_are_independent():
+    """configs[4] in miniature: several planning instances (own costmap seed, pose, plan, noise)
+    packed on one GPU; each must equal its own oracle, whatever the others do."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    from oracle.loader import Oracle
+    B, T, N = 2048, 64, 6
+    ctxs = []
+    for k in range(N):
+        cfg = default_config(batch_size=B, time_steps=T)
+        scn = make_scenario(T, seed=100 + k, warm_vx=0.2 + 0.03 * k)
+        noise = make_noise(B, T, seed=500 + k)
+        g, o = Smpc(cfg), Oracle(cfg)
+        for x in (g, o):
+            configure(x, scn, noise=noise)
+        ctxs.append((g, o, scn))
+    res = [g.optimize(scn.tick, scn.u0) for g, _, scn in ctxs]          # all N on the GPU
+    for k, (g, o, scn) in enumerate(ctxs):
+        uo, oo = o.optimize(scn.tick, scn.u0)
+        assert_parity(res[k][0], res[k][1], uo, oo, g.get_costs(), o.get_costs(),
+                      label=f"instance {k}")
+    assert len({tuple(np.round(r[0][:, 1], 5)) for r in res}) == N      # really different problems
+
+
+def test_fallback_counter_is_per_object():
+    """the reference's retry counter is function-static (shared by every Optimizer
+    in the process); here one instance failing does not touch another's."""
+    from mpcholonavigation_amd.host_optimizer import Optimizer
+    cfg = default_config(batch_size=256, time_steps=30)
+    bad_scn, good_scn = make_scenario(30, all_lethal=True), make_scenario(30)
+    bad = Optimizer(cfg, default_critics(), 20.0, retry_attempt_limit=3)
+    good = Optimizer(cfg, default_critics(), 20.0, retry_attempt_limit=3)
+    bad.set_costmap(bad_scn.cells, 0.0, 0.0, 0.05)
+    good.set_costmap(good_scn.cells, 0.0, 0.0, 0.05)
+    for _ in range(2):
+        with pytest.raises(RuntimeError):
+            bad.eval_control(bad_scn.tick)
+        tw, out = good.eval_control(good_scn.tick)
+        assert out.fail_flag == 0 and np.isfinite(tw).all()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 64, 65, 300, 1024])
+def test_path_length_edges(P):
+    """Plans from a single point to SMPC_MAX_PATH points (argmin over > 64 points, LDS staging)."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    from oracle.loader import Oracle
+    B, T = 512, 56
+    cfg = default_config(batch_size=B, time_steps=T)
+    scn = make_scenario(T)
+    noise = make_noise(B, T)
+    t = scn.tick
+    spacing = 2.9 / max(P - 1, 1)
+    px = (t.pose_x + spacing * np.arange(P)).astype(np.float32)
+    tick = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, px, np.full(P, t.pose_y, np.float32),
+                np.zeros(P, np.float32), float(px[-1]) + (3.0 if P == 1 else 0.0), t.pose_y)
+    g, o = Smpc(cfg), Oracle(cfg)
+    cr = default_critics()
+    cr.path_align.offset_from_furthest = 1 if P < 40 else 20
+    for x in (g, o):
+        configure(x, scn, critics=cr, noise=noise)
+    ug, og = g.optimize(tick, scn.u0)
+    uo, oo = o.optimize(tick, scn.u0)
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"P={P}", max_flips=1)
+
+
+def test_path_too_long_is_refused():
+    from mpcholonavigation_amd.optimizer import Smpc, SmpcError
+    cfg = default_config(batch_size=64, time_steps=30)
+    scn = make_scenario(30)
+    g = Smpc(cfg)
+    configure(g, scn, noise=make_noise(64, 30))
+    P = 1025
+    t = scn.tick
+    tick = Tick(t.pose_x, t.pose_y, 0.0, t.speed, np.linspace(2, 5, P).astype(np.float32),
+                np.full(P, 5, np.float32), np.zeros(P, np.float32), 5.0, 5.0)
+    with pytest.raises(SmpcError) as e:
+        g.optimize(tick, scn.u0)
+    assert e.value.code == A.SMPC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("T,step", [(64, 1), (64, 2), (64, 7), (128, 4), (256, 4), (200, 4), (30, 29)])
+def test_path_align_sampling_geometries(T, step):
+    """trajectory_point_step / horizon combinations: 1..63 samples per rollout, i.e. every
+    segment width (16/32/64 lanes) and group size of the flush."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    from oracle.loader import Oracle
+    B = 384
+    cfg = default_config(batch_size=B, time_steps=T)
+    scn = make_scenario(T)
+    noise = make_noise(B, T)
+    cr = default_critics()
+    cr.path_align.trajectory_point_step = step
+    cr.path_align.offset_from_furthest = 4
+    g, o = Smpc(cfg), Oracle(cfg)
+    for x in (g, o):
+        configure(x, scn, critics=cr, noise=noise)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"T={T} step={step}",
+                  max_flips=1)
+
+
+def test_too_many_path_align_samples_is_refused():
+    from mpcholonavigation_amd.optimizer import Smpc, SmpcError
+    cfg = default_config(batch_size=64, time_steps=128)
+    scn = make_scenario(128)
+    g = Smpc(cfg)
+    cr = default_critics()
+    cr.path_align.trajectory_point_step = 1          # 127 samples > 63
+    configure(g, scn, critics=cr, noise=make_noise(64, 128))
+    with pytest.raises(SmpcError) as e:
+        g.optimize(scn.tick, scn.u0)
+    assert e.value.code == A.SMPC_ERR_UNSUPPORTED
