@@ -285,6 +285,11 @@ int smpc_get_trajectories(smpc_ctx* ctx, float* x, float* y, float* yaws);
  * updateControlSequence) [ref include/.../optimizer.hpp:255]. */
 int smpc_get_costs(smpc_ctx* ctx, float* costs);
 
+/* Diagnostics: the device sin/cos the rollout uses (integrateStateVelocities,
+ * ref src/optimizer.cpp:326-329), evaluated on n host values; tests pin its error. */
+int smpc_selftest_sincos(smpc_ctx* ctx, const float* x, uint32_t n, float* sin_out,
+                         float* cos_out);
+
 /* ---- batch-sharded path; one ctx per GPU ------------------
  * A tick on G shards is
  *   begin -> [furthest -> MAX over ranks] -> score -> all-gather -> combine

@@ -37,6 +37,8 @@ hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, floa
 hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
 
+hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -1023,6 +1025,23 @@ int smpc_get_costs(smpc_ctx* c, float* costs)
   HIPCK(c, hipStreamSynchronize(c->stream));
   HIPCK(c, hipMemcpy(costs, c->d_costs[c->costs_cur], c->cfg.batch_size * sizeof(float),
                      hipMemcpyDeviceToHost));
+  return SMPC_OK;
+}
+
+int smpc_selftest_sincos(smpc_ctx* c, const float* x, uint32_t n, float* sin_out, float* cos_out)
+{
+  if (!c || !x || !sin_out || !cos_out || n == 0) return fail(c, SMPC_ERR_INVALID, "null argument");
+  HIPCK(c, hipSetDevice(c->device));
+  float *dx = nullptr, *ds = nullptr, *dc = nullptr;
+  HIPCK(c, hipMalloc(&dx, n * sizeof(float)));
+  HIPCK(c, hipMalloc(&ds, n * sizeof(float)));
+  HIPCK(c, hipMalloc(&dc, n * sizeof(float)));
+  HIPCK(c, hipMemcpyAsync(dx, x, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, smpc_launch_sincos(dx, n, ds, dc, c->stream));
+  HIPCK(c, hipMemcpyAsync(sin_out, ds, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipMemcpyAsync(cos_out, dc, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dc);
   return SMPC_OK;
 }
 

@@ -1141,6 +1141,27 @@ __global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, 
 }
 
 // ---------------------------------------------------------------------------
+// Self-test hook: the device sin/cos used by the rollout, evaluated on caller data.
+// ---------------------------------------------------------------------------
+__global__ void smpc_sincos_kernel(const float* __restrict__ x, uint32_t n,
+                                   float* __restrict__ sn, float* __restrict__ cs)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float s, c;
+    smpc_sincos(x[i], s, c);
+    sn[i] = s;
+    cs[i] = c;
+  }
+}
+
+hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, n, sn, cs);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // launch wrappers (called from smpc_api.cpp through plain C++ linkage)
 // ---------------------------------------------------------------------------
 template <int MODE, bool FULL>

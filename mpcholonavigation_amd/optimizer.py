@@ -143,6 +143,12 @@ class Smpc:
         self._ck(self.lib.smpc_get_costs(self.h, _ptr(c)))
         return c
 
+    def selftest_sincos(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        s, c = np.empty_like(x), np.empty_like(x)
+        self._ck(self.lib.smpc_selftest_sincos(self.h, _ptr(x), x.size, _ptr(s), _ptr(c)))
+        return s, c
+
     # ---- batch-sharded phases (device pointers are plain ints) ------------------
     def set_stream(self, hip_stream):
         self._ck(self.lib.smpc_set_stream(self.h, C.c_void_p(hip_stream)))
