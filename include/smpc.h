@@ -65,6 +65,9 @@ extern "C" {
                                              works [ref optimizer.cpp:455-458] */
 #define SMPC_FLAG_NO_SPECULATION 0x2u     /* always run the furthest-point
                                              pre-pass (exact two-pass mode)  */
+#define SMPC_FLAG_WAVE_PER_ROLLOUT 0x8u   /* the wave-per-rollout pass (the default)      */
+#define SMPC_FLAG_LANE_PER_ROLLOUT 0x10u  /* the alternative lane-per-rollout pass
+                                             (csrc/smpc_tpr.hip; opt-in)                 */
 #define SMPC_FLAG_PROFILE 0x4u            /* bracket each scoring pass with HIP
                                              events (smpc_tick_out.score_pass_ms) */
 

@@ -25,6 +25,8 @@ SMPC_MODEL_OMNI = 0
 SMPC_FLAG_STORE_TRAJECTORIES = 0x1
 SMPC_FLAG_NO_SPECULATION = 0x2
 SMPC_FLAG_PROFILE = 0x4
+SMPC_FLAG_WAVE_PER_ROLLOUT = 0x8
+SMPC_FLAG_LANE_PER_ROLLOUT = 0x10
 
 SMPC_TUPLE_HEADER = 4
 

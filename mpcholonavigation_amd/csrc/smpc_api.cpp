@@ -37,6 +37,11 @@ hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, floa
 hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
 
+hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
+hipError_t smpc_launch_pass_tpr(const SmpcDev& p, const SmpcLds& L, uint32_t grid, uint32_t block,
+                                hipStream_t st);
+hipError_t smpc_tpr_occupancy(int R, uint32_t block, uint32_t lds_bytes, int* blocks_per_cu);
+hipError_t smpc_tpr_set_lds_limit(int bytes);
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
 
 namespace {
@@ -44,6 +49,8 @@ namespace {
 thread_local std::string g_create_error;
 
 constexpr uint32_t kBlock = 512;          // threads per block of the streaming pass
+constexpr uint32_t kTprBlock = 256;       // lane-per-rollout pass: 4 waves x 64 rollouts
+constexpr uint32_t kTprMinBatch = 0xffffffffu;  // lane-per-rollout pass: opt-in only (see smpc_tpr.hip)
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
                                            // 0.05 m around the robot; the rest is read from HBM/L2
@@ -95,6 +102,13 @@ struct smpc_ctx {
   float* d_nvx = nullptr;
   float* d_nvy = nullptr;
   float* d_nwz = nullptr;
+  float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass
+  float* d_tvy = nullptr;
+  float* d_twz = nullptr;
+  bool use_tpr = false;
+  SmpcLds lds_tpr{};
+  uint32_t grid_tpr = 0;
+  uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
   float* d_costs[2] = {nullptr, nullptr};
   float* d_traj[3] = {nullptr, nullptr, nullptr};
   int costs_cur = 0;
@@ -167,7 +181,7 @@ void free_ctx(smpc_ctx* c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (float* p : {c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
+  for (float* p : {c->d_tvx, c->d_tvy, c->d_twz, c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
          c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
     if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
@@ -467,6 +481,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.yaw0 = yaw0; d.cos0 = cos0; d.sin0 = sin0;
   d.svx = svx; d.svy = svy; d.swz = swz; d.dt = dt;
   d.nvx = c->d_nvx; d.nvy = c->d_nvy; d.nwz = c->d_nwz;
+  d.tvx = c->d_tvx; d.tvy = c->d_tvy; d.twz = c->d_twz;
   d.u = reinterpret_cast<const float*>(c->d_tick + tl.u);
   d.traj_x = c->d_traj[0]; d.traj_y = c->d_traj[1]; d.traj_yaw = c->d_traj[2];
   d.map = c->d_map; d.W = c->map.W; d.H = c->map.H;
@@ -547,6 +562,23 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
+  if (c->use_tpr) {
+    // lane-per-rollout pass: same staging area, per wave {weights[64], U staging[3 Tpad]}
+    SmpcLds Lt = make_lds(window_bytes, P, T, kTprBlock / 64, window_bytes != 0, 0);
+    const uint32_t Tpad = (T + 15u) & ~15u;
+    Lt.scr_stride = align_up(std::max(64u + 3u * Tpad, 4u + 3u * T), 4);
+    Lt.total = Lt.off_scr + (kTprBlock / 64) * Lt.scr_stride * 4 + align_up(3 * T * 4, 16);
+    c->lds_tpr = Lt;
+    if (c->occ_tpr_lds != Lt.total) {
+      int nb = 0;
+      if (smpc_tpr_occupancy(c->R, kTprBlock, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
+      c->occ_tpr_blocks = static_cast<uint32_t>(nb);
+      c->occ_tpr_lds = Lt.total;
+    }
+    const uint32_t groups = (B + 63) / 64, wpb = kTprBlock / 64;
+    uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
+    c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
+  }
 
   c->gate_flags = gates;
   c->score_mode = mode_now;
@@ -584,7 +616,13 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   d.costs_prev = c->d_costs[c->costs_cur ^ 1];
   const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
   if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
-  HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, kBlock, c->stream));
+  uint32_t nblk = c->grid;
+  if (c->use_tpr) {
+    nblk = c->grid_tpr;
+    HIPCK(c, smpc_launch_pass_tpr(d, c->lds_tpr, nblk, kTprBlock, c->stream));
+  } else {
+    HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, kBlock, c->stream));
+  }
   if (prof) {
     HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
     c->evp_used += 2;
@@ -593,7 +631,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   fin.enabled = finish ? 1 : 0;
   fin.vx_max = c->c_vx_max; fin.vx_min = c->c_vx_min; fin.vy_max = c->c_vy; fin.wz_max = c->c_wz;
   fin.u_dev = c->d_out; fin.u_host = c->h_out_dev; fin.furthest_used = finish_furthest;
-  HIPCK(c, smpc_launch_reduce(c->d_partials, c->grid, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
+  HIPCK(c, smpc_launch_reduce(c->d_partials, nblk, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
   c->passes++;
   return SMPC_OK;
 }
@@ -635,6 +673,17 @@ uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky)
   return fail_sticky ? (c->gate_flags & keep) : c->gate_flags;
 }
 
+// keep the time-major copies in step with the [B,T] tensors
+int update_time_major(smpc_ctx* c)
+{
+  if (!c->use_tpr) return SMPC_OK;
+  const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
+  HIPCK(c, smpc_launch_transpose(c->d_nvx, c->d_tvx, B, T, c->stream));
+  HIPCK(c, smpc_launch_transpose(c->d_nvy, c->d_tvy, B, T, c->stream));
+  HIPCK(c, smpc_launch_transpose(c->d_nwz, c->d_twz, B, T, c->stream));
+  return SMPC_OK;
+}
+
 int draw_noise(smpc_ctx* c)
 {
   const uint64_t n = static_cast<uint64_t>(c->cfg.batch_size) * c->cfg.time_steps;
@@ -643,6 +692,8 @@ int draw_noise(smpc_ctx* c)
   HIPCK(c, smpc_launch_fill_noise(c->d_nvx, n, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
   HIPCK(c, smpc_launch_fill_noise(c->d_nwz, n, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
   HIPCK(c, smpc_launch_fill_noise(c->d_nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
+  int rc = update_time_major(c);
+  if (rc != SMPC_OK) return rc;
   HIPCK(c, hipStreamSynchronize(c->stream));
   c->have_noise = true;
   return SMPC_OK;
@@ -746,6 +797,25 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipMalloc(&c->d_nvx, n));
   CK(hipMalloc(&c->d_nvy, n));
   CK(hipMalloc(&c->d_nwz, n));
+  {
+    // which streaming pass: a wave per rollout (latency, small batches) or a lane per
+    // rollout (throughput, large batches); SMPC_PASS=wave|lane overrides for experiments
+    bool tpr = cfg->batch_size >= kTprMinBatch;
+    if (cfg->flags & SMPC_FLAG_WAVE_PER_ROLLOUT) tpr = false;
+    if (cfg->flags & SMPC_FLAG_LANE_PER_ROLLOUT) tpr = true;
+    if (const char* e = getenv("SMPC_PASS")) {
+      if (!strcmp(e, "wave")) tpr = false;
+      if (!strcmp(e, "lane")) tpr = true;
+    }
+    if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) tpr = false;   // visualisation path: wave pass
+    c->use_tpr = tpr;
+    if (tpr) {
+      CK(hipMalloc(&c->d_tvx, n));
+      CK(hipMalloc(&c->d_tvy, n));
+      CK(hipMalloc(&c->d_twz, n));
+      CK(smpc_tpr_set_lds_limit(static_cast<int>(kLdsPerCu)));
+    }
+  }
   CK(hipMalloc(&c->d_costs[0], cfg->batch_size * sizeof(float)));
   CK(hipMalloc(&c->d_costs[1], cfg->batch_size * sizeof(float)));
   CK(hipMemset(c->d_costs[0], 0, cfg->batch_size * sizeof(float)));
@@ -852,6 +922,10 @@ int smpc_set_noise(smpc_ctx* c, const float* nvx, const float* nvy, const float*
   HIPCK(c, hipMemcpyAsync(c->d_nvx, nvx, n, hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipMemcpyAsync(c->d_nvy, nvy, n, hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipMemcpyAsync(c->d_nwz, nwz, n, hipMemcpyHostToDevice, c->stream));
+  {
+    int rc = update_time_major(c);
+    if (rc != SMPC_OK) return rc;
+  }
   HIPCK(c, hipStreamSynchronize(c->stream));
   c->have_noise = true;
   c->rng_mode = false;

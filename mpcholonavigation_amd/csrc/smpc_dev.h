@@ -37,9 +37,12 @@ struct SmpcDev {
   float svx, svy, swz;
   float dt;
   // tensors
-  const float* nvx;
+  const float* nvx;         // noise [B,T] (reference layout; wave-per-rollout pass)
   const float* nvy;
   const float* nwz;
+  const float* tvx;         // the same noise time-major [T,B] (lane-per-rollout pass)
+  const float* tvy;
+  const float* twz;
   const float* u;           // [3T] control sequence (device)
   const float* costs_prev;  // [B] (SD_ACCUMULATE)
   float* costs;             // [B]

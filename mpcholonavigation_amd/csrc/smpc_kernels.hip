@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "smpc_dev.h"
+#include "smpc_device_math.h"
 
 #define WAVE 64
 
@@ -134,120 +135,6 @@ __device__ __forceinline__ float wave_shr1(float v, float first)
 __device__ __forceinline__ float lane_bcast(float v, int lane)
 {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// Keep a wave-uniform loop constant in a VGPR: the scoring loop has far more uniform
-// values than the 102 SGPRs hold, and what the compiler spills from SGPRs comes back as one
-// v_readlane per use.  VALU sources are free to be VGPRs.
-template <typename V>
-__device__ __forceinline__ V in_vgpr(V x)
-{
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
-// 1-ulp hardware sqrt / reciprocal (MODE 0: the terms they feed are continuous in
-// their inputs, so a last-bit difference moves a cost by ~1e-7 relative)
-__device__ __forceinline__ float fast_sqrt(float v) {return __builtin_amdgcn_sqrtf(v);}
-__device__ __forceinline__ float fast_rcp(float v) {return __builtin_amdgcn_rcpf(v);}
-
-// std::pow(double, unsigned) for the cost_power parameters (H5: pow promotes to double)
-__device__ __forceinline__ double powu(double v, uint32_t p)
-{
-  if (p == 1u) return v;
-  double r = 1.0;
-  while (p) {
-    if (p & 1u) r *= v;
-    v *= v;
-    p >>= 1;
-  }
-  return r;
-}
-// data.costs += xt::pow(v, power)
-__device__ __forceinline__ float add_cost_pow(float c, double v, uint32_t power)
-{
-  return (float)((double)c + powu(v, power));
-}
-
-// utils::normalize_angles (tools/utils.hpp:258-263), double like the reference
-__device__ __forceinline__ double normalize_angle(double a)
-{
-  const double theta = fmod(a + M_PI, 2.0 * M_PI);
-  return theta <= 0.0 ? theta + M_PI : theta - M_PI;
-}
-
-// sin and cos of a rollout yaw.  Cody–Waite reduction by pi/2 in three float
-// pieces (each fma is exact or correctly rounded on the cancelled difference)
-// and the Cephes single-precision minimax polynomials on [-pi/4, pi/4];
-// <= ~1 ulp.  Huge arguments take the library path.
-__device__ __forceinline__ void smpc_sincos(float x, float& sn, float& cs)
-{
-  if (__builtin_expect(!(fabsf(x) < 65536.0f), 0)) {
-    sincosf(x, &sn, &cs);
-    return;
-  }
-  const float k = rintf(x * 0.6366197466850281f);
-  float r = fmaf(-k, 1.5707963705062866f, x);
-  r = fmaf(-k, -4.371138828673793e-08f, r);
-  r = fmaf(-k, -1.7151245100058819e-15f, r);
-  const float z = r * r;
-  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
-  ps = fmaf(ps, z, -1.6666654611e-1f);
-  const float s = fmaf(ps * z, r, r);
-  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
-  pc = fmaf(pc, z, 4.166664568298827e-2f);
-  const float c = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));
-  const int q = (int)k;
-  const float a = (q & 1) ? c : s;
-  const float b = (q & 1) ? s : c;
-  sn = (q & 2) ? -a : a;
-  cs = ((q + 1) & 2) ? -b : b;
-}
-
-// Costmap2D::worldToMap along one axis, exactly as nav2_costmap_2d does it:
-// reject w < origin, else (unsigned)((w - origin) / resolution) in double.
-__device__ __forceinline__ bool cell_index_exact(double w, double o, double res, uint32_t n,
-                                                 uint32_t& m)
-{
-  if (w < o) return false;
-  const double q = (w - o) / res;
-  if (!(q < 4294967296.0)) return false;  // the reference's cast would be UB: off-map
-  m = (uint32_t)q;
-  return m < n;
-}
-
-// Costmap2D::worldToMap + getCost through the LDS window (global fallback).
-// Off-map -> NO_INFORMATION (obstacles_critic.cpp:209-212).
-//
-// The cell index is first formed in float, q = (x - origin_f) * (1/res)_f, whose
-// distance to the double quotient the reference truncates is bounded by
-// p.cell_eps (host: origin rounding + 3 float roundings).  Only a lane whose q
-// lies within that bound of a cell edge can truncate differently; those lanes
-// (a fraction ~4*cell_eps) redo both axes in double with the true division, so
-// every lookup reads the cell the reference reads.
-struct CellConsts {   // loop constants of cost_at, held in VGPRs
-  float oxf, oyf, rinvf, lo, hi;
-};
-__device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const CellConsts& k,
-                                            const uint8_t* s_map, float x, float y)
-{
-  const float qx = (x - k.oxf) * k.rinvf, qy = (y - k.oyf) * k.rinvf;
-  const float fx = floorf(qx), fy = floorf(qy);
-  const float rx = qx - fx, ry = qy - fy;
-  const float lo = k.lo, hi = k.hi;
-  uint32_t mx = (uint32_t)(int)fx, my = (uint32_t)(int)fy;   // negative / huge -> >= W
-  bool on = mx < p.W && my < p.H;
-  if (__builtin_expect(!(rx >= lo && rx <= hi && ry >= lo && ry <= hi), 0)) {
-    on = cell_index_exact((double)x, p.ox, p.res, p.W, mx);
-    on = cell_index_exact((double)y, p.oy, p.res, p.H, my) && on;
-  }
-  if (!on) return 255u;
-  const uint32_t lx = mx - (uint32_t)p.win_x0, ly = my - (uint32_t)p.win_y0;
-  // two separate loads (never a select of an LDS and a global pointer)
-  const bool inw = lx < (uint32_t)p.win_w && ly < (uint32_t)p.win_h;
-  uint32_t c = s_map[inw ? ly * p.win_w + lx : 0u];
-  if (__builtin_expect(!inw, 0)) c = p.map[(size_t)my * p.W + mx];
-  return c;
 }
 
 // max over the parked endpoints of argmin_j |path_j - endpoint|^2 (first minimum wins)

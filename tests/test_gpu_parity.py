@@ -324,3 +324,19 @@ def test_device_sincos_accuracy(Smpc):
         small = np.abs(ref) > 1e-3          # relative accuracy where the value is not ~0
         assert err[small].max() <= 1.6, err[small].max()
         assert np.max(np.abs(got.astype(np.float64) - ref)) < 1.2e-7
+
+
+@pytest.mark.parametrize("B,T,M", [(1000, 30, 200), (4096, 64, 200), (2500, 100, 200),
+                                   (2048, 128, 2000), (300, 200, 200), (65, 3, 200)])
+def test_lane_per_rollout_pass_parity(Smpc, Oracle, B, T, M):
+    """The alternative pass (lane = rollout, sequential in time, MFMA weighted sum;
+    csrc/smpc_tpr.hip) against the oracle, cruise and near-goal."""
+    for near in (False, True):
+        cfg, scn, noise = make_case(B, T, map_size=M, near_goal=near)
+        cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+        g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+        assert og.non_colliding == oo.non_colliding
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1,
+                      label=f"lane pass {B}x{T} near={near}")
+    # its rollouts run in the reference's sequential order: most costs are bit-identical
+    assert np.mean(g.get_costs() == o.get_costs()) > 0.5
