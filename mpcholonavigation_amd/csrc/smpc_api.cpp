@@ -546,7 +546,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
 
   // persistent grid: as many blocks as stay resident, never more than the work
   const uint32_t waves_per_block = kBlock / 64;
-  const int mode_now = c->score_mode_for(cr);
+  int mode_now = c->score_mode_for(cr);
+  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE)) mode_now = 2;   // lean kernel lacks these
   if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
     int nb = 0;
     if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), kBlock, c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;

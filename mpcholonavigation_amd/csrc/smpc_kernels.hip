@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pas
 {
   constexpr bool FURTHEST_ONLY = MODE == 1;
   constexpr bool GENERIC = MODE == 2;
+  // MODE 0 is the lean kernel: the rarely used features (trajectory write-out, path
+  // orientations, the near-goal GoalAngle term) live only in MODE 2, so their pointers and
+  // parameters do not occupy scalar registers in the hot loop
+  constexpr bool RARE = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
@@ -455,7 +459,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pas
       float d = 0.f;
       if (ok) {
         const float ddx = s_px[pt] - Tx, ddy = s_py[pt] - Ty;
-        if (p.flags & SD_USE_PATH_YAW) {
+        if (RARE && (p.flags & SD_USE_PATH_YAW)) {
           const double dd = (double)pts_yaw[lane] - (double)s_pyaw[pt];
           double a = fmod(fmod(dd, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
           if (a > M_PI) a -= 2.0 * M_PI;
@@ -610,7 +614,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pas
         }
       }
     }
-    if (!FURTHEST_ONLY && (p.flags & SD_STORE_TRAJ)) {
+    if (!FURTHEST_ONLY && (RARE && (p.flags & SD_STORE_TRAJ))) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (STEP_OK(r)) {
@@ -706,7 +710,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pas
     }
 
     // ---- GoalAngleCritic (goal_angle_critic.cpp:36-50) -----------------------
-    if (p.flags & SD_GOAL_ANGLE) {
+    if (RARE && (p.flags & SD_GOAL_ANGLE)) {
       double sa = 0.0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -762,7 +766,7 @@ __global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pas
           const uint32_t q = (n_pend << seg_shift) + (uint32_t)slot[r];
           pts_x[q] = x[r];
           pts_y[q] = y[r];
-          if (p.flags & SD_USE_PATH_YAW) pts_yaw[q] = yaw[r];
+          if (RARE && (p.flags & SD_USE_PATH_YAW)) pts_yaw[q] = yaw[r];
         }
       }
       if (((uint32_t)lane >> seg_shift) == n_pend) pend_cost = cost;
