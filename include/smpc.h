@@ -189,8 +189,8 @@ typedef struct smpc_tick_out {
   float sum_w;              /* sum of exp weights of the last iteration            */
   uint32_t passes;          /* scoring passes over the noise (speculation misses
                                show up as passes > iteration_count)               */
-  float device_ms;          /* GPU time of this call, first upload to last kernel
-                               (HIP events on the ctx's stream)                     */
+  float device_ms;          /* SMPC_FLAG_PROFILE: GPU time of this call, first upload to
+                               last kernel (HIP events on the ctx's stream); else 0 */
   float score_pass_ms;      /* SMPC_FLAG_PROFILE: mean GPU time of one scoring-pass
                                kernel (smpc_pass) of this call, HIP events around it */
 } smpc_tick_out;

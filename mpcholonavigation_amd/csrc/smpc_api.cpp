@@ -48,7 +48,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr uint32_t kBlock = 512;          // threads per block of the streaming pass
+// threads per block of the streaming pass: 16 waves share one costmap window and produce one
+// partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
+inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
 constexpr uint32_t kTprBlock = 256;       // lane-per-rollout pass: 4 waves x 64 rollouts
 constexpr uint32_t kTprMinBatch = 0xffffffffu;  // lane-per-rollout pass: opt-in only (see smpc_tpr.hip)
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
@@ -158,6 +160,9 @@ struct smpc_ctx {
   bool hint_valid = false;
   uint32_t hint = 0;
   uint64_t spec_misses = 0;
+  // completion polling on the host-mapped result (SMPC_NO_POLL=1 disables)
+  bool poll_enabled = true;
+  uint32_t seq = 0, poll_seq = 0;
   std::string err;
 };
 
@@ -470,7 +475,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     }
   }
 
-  HIPCK(c, hipEventRecord(c->ev0, c->stream));
+  if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev0, c->stream));
   HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
 
   // ---- kernel parameter block ------------------------------------------------------
@@ -541,16 +546,16 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     d.win_w = static_cast<int32_t>(ww); d.win_h = static_cast<int32_t>(wh);
     window_bytes = ww * wh;
   }
-  c->lds = make_lds(window_bytes, P, T, kBlock / 64, window_bytes != 0, nsamp);
+  c->lds = make_lds(window_bytes, P, T, (pass_block(c->R) / 64), window_bytes != 0, nsamp);
   if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
 
   // persistent grid: as many blocks as stay resident, never more than the work
-  const uint32_t waves_per_block = kBlock / 64;
+  const uint32_t waves_per_block = (pass_block(c->R) / 64);
   int mode_now = c->score_mode_for(cr);
   if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE)) mode_now = 2;   // lean kernel lacks these
   if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
     int nb = 0;
-    if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), kBlock, c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
+    if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), pass_block(c->R), c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
     c->occ_blocks = static_cast<uint32_t>(nb);
     c->occ_lds = c->lds.total;
     c->occ_mode = mode_now;
@@ -595,8 +600,8 @@ int launch_furthest(smpc_ctx* c, float* d_furthest)
   SmpcDev d = c->dev;
   d.flags = c->gate_flags & SD_NEED_FURTHEST;
   d.furthest_out = reinterpret_cast<uint32_t*>(d_furthest);
-  SmpcLds L = make_lds(0, c->P, d.T, kBlock / 64, false);
-  HIPCK(c, smpc_launch_pass(c->R, 1, d, L, c->grid, kBlock, c->stream));
+  SmpcLds L = make_lds(0, c->P, d.T, (pass_block(c->R) / 64), false);
+  HIPCK(c, smpc_launch_pass(c->R, 1, d, L, c->grid, pass_block(c->R), c->stream));
   return SMPC_OK;
 }
 
@@ -622,7 +627,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
     nblk = c->grid_tpr;
     HIPCK(c, smpc_launch_pass_tpr(d, c->lds_tpr, nblk, kTprBlock, c->stream));
   } else {
-    HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, kBlock, c->stream));
+    HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, pass_block(c->R), c->stream));
   }
   if (prof) {
     HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
@@ -632,6 +637,12 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   fin.enabled = finish ? 1 : 0;
   fin.vx_max = c->c_vx_max; fin.vx_min = c->c_vx_min; fin.vy_max = c->c_vy; fin.wz_max = c->c_wz;
   fin.u_dev = c->d_out; fin.u_host = c->h_out_dev; fin.furthest_used = finish_furthest;
+  if (finish && c->poll_enabled) {
+    fin.done_counter = reinterpret_cast<uint32_t*>(c->d_furthest) + 2;
+    fin.seq = ++c->seq;
+    if (fin.seq == 0) fin.seq = ++c->seq;
+    c->poll_seq = fin.seq;
+  }
   HIPCK(c, smpc_launch_reduce(c->d_partials, nblk, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
   c->passes++;
   return SMPC_OK;
@@ -648,7 +659,22 @@ int launch_combine(smpc_ctx* c, const float* d_tuples, uint32_t n, const float* 
 
 int fetch_out(smpc_ctx* c)
 {
-  // the finishing kernel wrote u and the result into host-mapped memory: just wait
+  // The finishing kernel wrote u and the result into host-mapped memory and then the
+  // tick's sequence number: spin on that word (a few microseconds sooner than the
+  // runtime's stream wait), and fall back to the stream wait, which also surfaces errors.
+  if (c->poll_seq) {
+    const volatile uint32_t* flag =
+      reinterpret_cast<const volatile uint32_t*>(c->h_out + 3 * c->cfg.time_steps + 7);
+    const uint32_t want = c->poll_seq;
+    c->poll_seq = 0;
+    for (uint32_t spin = 0; spin < 4000000u; ++spin) {
+      if (*flag == want) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return SMPC_OK;
+      }
+      __builtin_ia32_pause();
+    }
+  }
   HIPCK(c, hipStreamSynchronize(c->stream));
   return SMPC_OK;
 }
@@ -789,6 +815,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  c->poll_enabled = getenv("SMPC_NO_POLL") == nullptr;
   CK(hipEventCreate(&c->ev0));
   CK(hipEventCreate(&c->ev1));
   if (cfg->flags & SMPC_FLAG_PROFILE) for (auto& e : c->evp) CK(hipEventCreate(&e));
@@ -1012,7 +1039,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     }
     rc = launch_score(c, flags, u_dev, dF, hintS, c->d_tuple, true, dF);
     if (rc != SMPC_OK) return rc;
-    HIPCK(c, hipEventRecord(c->ev1, c->stream));
+    if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev1, c->stream));
     fetched = false;
     const bool last = it + 1 == c->cfg.iteration_count;
     if ((flags & SD_OBSTACLES) || spec_try || last) {
@@ -1035,7 +1062,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
         flags &= ~SD_LOCAL_FURTHEST;
         rc = launch_score(c, flags, u_dev, nullptr, S_host, c->d_tuple, true, nullptr);
         if (rc != SMPC_OK) return rc;
-        HIPCK(c, hipEventRecord(c->ev1, c->stream));
+        if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev1, c->stream));
         rc = fetch_out(c);
         if (rc != SMPC_OK) return rc;
       }
@@ -1050,7 +1077,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
         (it > 0 ? SD_ACCUMULATE : 0u);
       rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple, true, nullptr);
       if (rc != SMPC_OK) return rc;
-      HIPCK(c, hipEventRecord(c->ev1, c->stream));
+      if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev1, c->stream));
       fetched = false;
     }
   }
@@ -1073,7 +1100,11 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     out->sum_w = c->h_out[3 * T + 1];
     out->passes = c->passes;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->device_ms = ms;
+    if (c->cfg.flags & SMPC_FLAG_PROFILE) {
+      // the polled flag can beat the event's completion signal by a few microseconds
+      HIPCK(c, hipEventSynchronize(c->ev1));
+      if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->device_ms = ms;
+    }
     out->score_pass_ms = profile_pass_ms(c);
   }
   return SMPC_OK;

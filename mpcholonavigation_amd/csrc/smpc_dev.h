@@ -96,6 +96,8 @@ struct SmpcFinal {
   float* u_dev;                            // [3T + 8] device copy (next iteration reads u here)
   float* u_host;                           // [3T + 8] host-mapped copy (no D2H memcpy)
   const float* furthest_used;              // device float or null
+  uint32_t* done_counter;                  // device word, zero between launches
+  uint32_t seq;                            // tick sequence number published at u_host[3T+7]
 };
 
 // LDS carve-up, computed once on the host and passed to the kernel.

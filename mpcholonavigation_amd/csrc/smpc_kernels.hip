@@ -230,7 +230,7 @@ __device__ __forceinline__ float seg_scan_add(float v, uint32_t seg_shift)
 // then the weighted controls of the group are accumulated.
 // ---------------------------------------------------------------------------
 template <int R, int MODE, bool FULL>
-__global__ void __launch_bounds__(512, (R == 1 ? 4 : (R == 2 ? 3 : 2))) smpc_pass(const SmpcDev p, const SmpcLds L)
+__global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_pass(const SmpcDev p, const SmpcLds L)
 {
   constexpr bool FURTHEST_ONLY = MODE == 1;
   constexpr bool GENERIC = MODE == 2;
@@ -929,6 +929,21 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
           fin.u_dev[3 * T + k] = res[k];
           fin.u_host[3 * T + k] = res[k];
         }
+      }
+    }
+  }
+  // completion flag for the polling host: the block that finishes last publishes the tick's
+  // sequence number behind a system-scope fence (every block's host stores precede it)
+  if (fin.enabled && fin.done_counter) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t prev = atomicAdd(fin.done_counter, 1u);
+      if (prev + 1u == gridDim.x) {
+        *fin.done_counter = 0u;   // ready for the next launch (same stream: ordered)
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(fin.u_host + 3 * T + 7), fin.seq,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
