@@ -67,7 +67,7 @@ def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0)
     from mpcholonavigation_amd.optimizer import Smpc
     from mpcholonavigation_amd.synthetic import make_scenario
     from mpcholonavigation_amd.tick import default_config, default_critics
-    cfg = default_config(batch_size=B, time_steps=T, flags=flags | A.SMPC_FLAG_PROFILE,
+    cfg = default_config(batch_size=B, time_steps=T, flags=flags,
                          shard_offset=shard_offset, global_batch_size=global_batch)
     scn = make_scenario(T, map_size=map_size)
     g = Smpc(cfg)
@@ -105,8 +105,11 @@ def run_ticks(step_fn, scn, steps, warmup, sync, barrier):
 def time_config(B, T, map_size, steps, warmup):
     import torch
     g, scn, cfg = make_ctx(B, T, map_size)
-    el, pass_ms, dev_ms, passes, out = run_ticks(g.optimize, scn, steps, warmup,
-                                                 torch.cuda.synchronize, lambda: None)
+    el, _, _, passes, out = run_ticks(g.optimize, scn, steps, warmup,
+                                      torch.cuda.synchronize, lambda: None)
+    g.set_profile(True)
+    _, pass_ms, dev_ms, _, _ = run_ticks(g.optimize, scn, steps, 2, torch.cuda.synchronize,
+                                         lambda: None)
     P = len(scn.tick.path_x)
     by = algorithmic_bytes(B, T, map_size, map_size, P)
     r = {
@@ -219,8 +222,15 @@ def main():
         def barrier():
             pass
 
-    el, pass_ms, dev_ms, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
-                                                 torch.cuda.synchronize, barrier)
+    # the timed region: exactly K ticks, no event records in the stream
+    el, _, _, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
+                                      torch.cuda.synchronize, barrier)
+    # kernel duration for the roofline: the same K ticks again with HIP events around every
+    # scoring-pass launch, on the stream it is launched on (SMPC_FLAG_PROFILE; the event
+    # records cost ~15 us of queue time per tick, which is why they are not in the region above)
+    g.set_profile(True)
+    el_prof, pass_ms, dev_ms, _, _ = run_ticks(step_fn, scn, args.steps, 2,
+                                               torch.cuda.synchronize, barrier)
     if world > 1 or force_dist:
         t = torch.tensor([el, pass_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,6 +272,8 @@ def main():
                 "algorithmic_bytes_per_launch": by,
                 "avg_launch_ms": pass_ms,
                 "device_ms_per_tick": dev_ms,
+                "timing": f"HIP events around each smpc_pass launch over {args.steps} further ticks "
+                          f"({1e3 * el_prof / args.steps:.4f} ms/tick with the event records in the stream)",
             },
         }
         if world == 1 and not args.no_other_configs:

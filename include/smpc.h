@@ -309,6 +309,10 @@ int smpc_selftest_sincos(smpc_ctx* ctx, const float* x, uint32_t n, float* sin_o
 #define SMPC_STREAM_OWN ((void*)(intptr_t)-1)
 int smpc_set_stream(smpc_ctx* ctx, void* hip_stream);
 
+/* Turn SMPC_FLAG_PROFILE on/off after creation (event records cost ~15 us of host and
+ * queue time per tick, so throughput is measured with it off). */
+int smpc_set_profile(smpc_ctx* ctx, int enable);
+
 #define SMPC_TUPLE_HEADER 4 /* floats before U: min, sum_w, furthest, non_colliding */
 /* Length in floats of one shard tuple: SMPC_TUPLE_HEADER + 3*T. */
 uint32_t smpc_tuple_len(const smpc_ctx* ctx);

@@ -818,7 +818,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   c->poll_enabled = getenv("SMPC_NO_POLL") == nullptr;
   CK(hipEventCreate(&c->ev0));
   CK(hipEventCreate(&c->ev1));
-  if (cfg->flags & SMPC_FLAG_PROFILE) for (auto& e : c->evp) CK(hipEventCreate(&e));
+  for (auto& e : c->evp) CK(hipEventCreate(&e));
   const uint32_t T = cfg->time_steps;
   c->R = T <= 64 ? 1 : (T <= 128 ? 2 : 4);
   const size_t n = static_cast<size_t>(cfg->batch_size) * T * sizeof(float);
@@ -1157,6 +1157,14 @@ int smpc_set_stream(smpc_ctx* c, void* hip_stream)
 {
   if (!c) return SMPC_ERR_INVALID;
   c->stream = hip_stream == SMPC_STREAM_OWN ? c->own_stream : static_cast<hipStream_t>(hip_stream);
+  return SMPC_OK;
+}
+
+int smpc_set_profile(smpc_ctx* c, int enable)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (enable) c->cfg.flags |= SMPC_FLAG_PROFILE;
+  else c->cfg.flags &= ~static_cast<uint32_t>(SMPC_FLAG_PROFILE);
   return SMPC_OK;
 }
 

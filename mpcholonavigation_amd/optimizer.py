@@ -153,6 +153,10 @@ class Smpc:
     def set_stream(self, hip_stream):
         self._ck(self.lib.smpc_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def set_profile(self, enable):
+        """SMPC_FLAG_PROFILE on/off: HIP events around the scoring pass (costs ~15 us/tick)."""
+        self._ck(self.lib.smpc_set_profile(self.h, int(bool(enable))))
+
     @property
     def tuple_len(self):
         return self.lib.smpc_tuple_len(self.h)
