@@ -65,9 +65,10 @@ extern "C" {
                                              works [ref optimizer.cpp:455-458] */
 #define SMPC_FLAG_NO_SPECULATION 0x2u     /* always run the furthest-point
                                              pre-pass (exact two-pass mode)  */
-#define SMPC_FLAG_WAVE_PER_ROLLOUT 0x8u   /* the wave-per-rollout pass (the default)      */
-#define SMPC_FLAG_LANE_PER_ROLLOUT 0x10u  /* the alternative lane-per-rollout pass
-                                             (csrc/smpc_tpr.hip; opt-in)                 */
+#define SMPC_FLAG_WAVE_PER_ROLLOUT 0x8u   /* always the wave-per-rollout pass             */
+#define SMPC_FLAG_LANE_PER_ROLLOUT 0x10u  /* the lane-per-rollout pass (csrc/smpc_lane.hip)
+                                             on every tick it supports: time_steps <= 64,
+                                             every cost_power 1, no GoalAngle term active */
 #define SMPC_FLAG_PROFILE 0x4u            /* bracket each scoring pass with HIP
                                              events (smpc_tick_out.score_pass_ms) */
 
@@ -292,6 +293,10 @@ int smpc_get_costs(smpc_ctx* ctx, float* costs);
  * ref src/optimizer.cpp:326-329), evaluated on n host values; tests pin its error. */
 int smpc_selftest_sincos(smpc_ctx* ctx, const float* x, uint32_t n, float* sin_out,
                          float* cos_out);
+/* Diagnostics: the in-register 64 x 64 transpose-reduce of the lane-per-rollout pass
+ * (updateControlSequence's weighted sum, ref src/optimizer.cpp:382-393):
+ * out[t] = sum_b w[b] * v[b*64 + t], b, t = 0..63. */
+int smpc_selftest_lane_reduce(smpc_ctx* ctx, const float* v, const float* w, float* out);
 
 /* ---- batch-sharded path; one ctx per GPU ------------------
  * A tick on G shards is

@@ -182,6 +182,7 @@ PROTOTYPES = {
     "smpc_get_trajectories": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smpc_get_costs": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_selftest_sincos": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "smpc_selftest_lane_reduce": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smpc_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_set_profile": (C.c_int, [_ctx, C.c_int]),
     "smpc_tuple_len": (C.c_uint32, [_ctx]),

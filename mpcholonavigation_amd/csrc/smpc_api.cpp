@@ -38,10 +38,11 @@ hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
 
 hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
-hipError_t smpc_launch_pass_tpr(const SmpcDev& p, const SmpcLds& L, uint32_t grid, uint32_t block,
-                                hipStream_t st);
-hipError_t smpc_tpr_occupancy(int R, uint32_t block, uint32_t lds_bytes, int* blocks_per_cu);
-hipError_t smpc_tpr_set_lds_limit(int bytes);
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st);
+uint32_t smpc_lane_block();
+hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu);
+hipError_t smpc_lane_set_lds_limit(int bytes);
+hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
 
 namespace {
@@ -51,8 +52,8 @@ thread_local std::string g_create_error;
 // threads per block of the streaming pass: 16 waves share one costmap window and produce one
 // partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
 inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
-constexpr uint32_t kTprBlock = 256;       // lane-per-rollout pass: 4 waves x 64 rollouts
-constexpr uint32_t kTprMinBatch = 0xffffffffu;  // lane-per-rollout pass: opt-in only (see smpc_tpr.hip)
+constexpr uint32_t kLaneMinBatch = 0xffffffffu;  // lane-per-rollout pass from this batch size up
+constexpr uint32_t kLaneMaxT = 64;        // it parks 3 x 64 noised controls per lane in registers
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
                                            // 0.05 m around the robot; the rest is read from HBM/L2
@@ -107,7 +108,8 @@ struct smpc_ctx {
   float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass
   float* d_tvy = nullptr;
   float* d_twz = nullptr;
-  bool use_tpr = false;
+  bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
+  bool lane_now = false;     // ... and does for this tick (lean scoring mode)
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
@@ -492,6 +494,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.map = c->d_map; d.W = c->map.W; d.H = c->map.H;
   d.ox = c->map.ox; d.oy = c->map.oy; d.res = c->map.res;
   d.cost_t0 = cost_t0;
+  d.x00f = x00; d.y00f = y00;
   {
     // fast cell index: float quotient + guard band (see cost_at in smpc_kernels.hip)
     const double rinv = 1.0 / c->map.res;
@@ -568,22 +571,39 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
-  if (c->use_tpr) {
-    // lane-per-rollout pass: same staging area, per wave {weights[64], U staging[3 Tpad]}
-    SmpcLds Lt = make_lds(window_bytes, P, T, kTprBlock / 64, window_bytes != 0, 0);
-    const uint32_t Tpad = (T + 15u) & ~15u;
-    Lt.scr_stride = align_up(std::max(64u + 3u * Tpad, 4u + 3u * T), 4);
-    Lt.total = Lt.off_scr + (kTprBlock / 64) * Lt.scr_stride * 4 + align_up(3 * T * 4, 16);
+  c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
+  if (c->lane_now) {
+    // lane-per-rollout pass: same staging area; per wave only the block-combine slot
+    const uint32_t lblock = smpc_lane_block();
+    // window + the NO_INFORMATION byte + one scratch byte per lane (cell_byte_exact)
+    SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
+                          window_bytes != 0, 0);
+    Lt.scr_stride = align_up(std::max(64u * 65u + 64u, 4u + 3u * T), 4);   // parked wz + weights
+    Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
     c->lds_tpr = Lt;
     if (c->occ_tpr_lds != Lt.total) {
       int nb = 0;
-      if (smpc_tpr_occupancy(c->R, kTprBlock, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
+      if (smpc_lane_occupancy(T == 64, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
       c->occ_tpr_blocks = static_cast<uint32_t>(nb);
       c->occ_tpr_lds = Lt.total;
     }
-    const uint32_t groups = (B + 63) / 64, wpb = kTprBlock / 64;
+    const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
     uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
     c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
+    // window-relative float cell index and its guard band (cost_at_lane)
+    const double rinv = 1.0 / c->map.res;
+    const double wx = c->map.ox + static_cast<double>(d.win_x0) * c->map.res;
+    const double wy = c->map.oy + static_cast<double>(d.win_y0) * c->map.res;
+    d.wxf = static_cast<float>(wx);
+    d.wyf = static_cast<float>(wy);
+    const double e_o = std::max(std::fabs(wx - static_cast<double>(d.wxf)),
+                                std::fabs(wy - static_cast<double>(d.wyf)));
+    // the reference divides (x - origin) by the resolution; the window corner is
+    // origin + win0 * res in double: one more rounding of that product and sum
+    const double e_c = 2.3e-16 * (std::fabs(wx) + std::fabs(wy) + 1.0);
+    const double qmax = static_cast<double>(std::max(d.win_w, d.win_h)) + 2.0;
+    const double eps = 2.0 * ((e_o + e_c) * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
+    d.cell_eps_w = static_cast<float>(std::min(eps, 0.5));
   }
 
   c->gate_flags = gates;
@@ -623,9 +643,10 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
   if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
   uint32_t nblk = c->grid;
-  if (c->use_tpr) {
+  // the lane-per-rollout pass scores with the full lean critic stack only
+  if (c->lane_now && !(flags & SD_STORE_TRAJ)) {
     nblk = c->grid_tpr;
-    HIPCK(c, smpc_launch_pass_tpr(d, c->lds_tpr, nblk, kTprBlock, c->stream));
+    HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->stream));
   } else {
     HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, pass_block(c->R), c->stream));
   }
@@ -828,7 +849,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   {
     // which streaming pass: a wave per rollout (latency, small batches) or a lane per
     // rollout (throughput, large batches); SMPC_PASS=wave|lane overrides for experiments
-    bool tpr = cfg->batch_size >= kTprMinBatch;
+    bool tpr = cfg->batch_size >= kLaneMinBatch && cfg->time_steps <= kLaneMaxT;
     if (cfg->flags & SMPC_FLAG_WAVE_PER_ROLLOUT) tpr = false;
     if (cfg->flags & SMPC_FLAG_LANE_PER_ROLLOUT) tpr = true;
     if (const char* e = getenv("SMPC_PASS")) {
@@ -841,7 +862,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
       CK(hipMalloc(&c->d_tvx, n));
       CK(hipMalloc(&c->d_tvy, n));
       CK(hipMalloc(&c->d_twz, n));
-      CK(smpc_tpr_set_lds_limit(static_cast<int>(kLdsPerCu)));
+      CK(smpc_lane_set_lds_limit(static_cast<int>(kLdsPerCu)));
     }
   }
   CK(hipMalloc(&c->d_costs[0], cfg->batch_size * sizeof(float)));
@@ -1148,6 +1169,23 @@ int smpc_selftest_sincos(smpc_ctx* c, const float* x, uint32_t n, float* sin_out
   HIPCK(c, hipMemcpyAsync(cos_out, dc, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
   (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dc);
+  return SMPC_OK;
+}
+
+int smpc_selftest_lane_reduce(smpc_ctx* c, const float* v, const float* w, float* out)
+{
+  if (!c || !v || !w || !out) return fail(c, SMPC_ERR_INVALID, "null argument");
+  HIPCK(c, hipSetDevice(c->device));
+  float *dv = nullptr, *dw = nullptr, *dout = nullptr;
+  HIPCK(c, hipMalloc(&dv, 64 * 64 * sizeof(float)));
+  HIPCK(c, hipMalloc(&dw, 64 * sizeof(float)));
+  HIPCK(c, hipMalloc(&dout, 64 * sizeof(float)));
+  HIPCK(c, hipMemcpyAsync(dv, v, 64 * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(dw, w, 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, smpc_launch_lane_reduce(dv, dw, dout, c->stream));
+  HIPCK(c, hipMemcpyAsync(out, dout, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dv); (void)hipFree(dw); (void)hipFree(dout);
   return SMPC_OK;
 }
 

@@ -57,6 +57,9 @@ struct SmpcDev {
   float cell_eps;          // bound on |float quotient - double quotient| (guard band)
   uint32_t cost_t0;        // costmap cost under trajectory point 0 (same for every rollout)
   int32_t win_x0, win_y0, win_w, win_h;  // window staged in LDS (cells)
+  float wxf, wyf;          // float images of the window corner (lane-per-rollout pass)
+  float cell_eps_w;        // guard band for the window-relative quotient
+  float x00f, y00f;        // trajectory point 0 (identical for every rollout)
   const SmpcLut* lut;                     // [256]
   // path block (device)
   const float* px;

@@ -52,12 +52,18 @@ __device__ __forceinline__ double normalize_angle(double a)
 // pieces (each fma is exact or correctly rounded on the cancelled difference)
 // and the Cephes single-precision minimax polynomials on [-pi/4, pi/4];
 // <= ~1 ulp.  Huge arguments take the library path.
+__device__ __forceinline__ void smpc_sincos_fast(float x, float& sn, float& cs);
 __device__ __forceinline__ void smpc_sincos(float x, float& sn, float& cs)
 {
   if (__builtin_expect(!(fabsf(x) < 65536.0f), 0)) {
     sincosf(x, &sn, &cs);
     return;
   }
+  smpc_sincos_fast(x, sn, cs);
+}
+// |x| < 65536 only (the caller checks)
+__device__ __forceinline__ void smpc_sincos_fast(float x, float& sn, float& cs)
+{
   const float k = rintf(x * 0.6366197466850281f);
   float r = fmaf(-k, 1.5707963705062866f, x);
   r = fmaf(-k, -4.371138828673793e-08f, r);

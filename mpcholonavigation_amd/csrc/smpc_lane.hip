@@ -1,0 +1,690 @@
+// smpc_lane.hip — the streaming pass with one LANE per rollout (T <= 64, lean critics).
+//
+// smpc_kernels.hip gives every rollout a whole wavefront (lane = time step): the lowest
+// latency and the right shape for the reference's deployed batch (2 000 rollouts), but it
+// pays ~35 cross-lane DPP steps and a lot of per-rollout scalar work executed 64 lanes wide.
+// On CDNA4 a wave64 VALU instruction costs 4 cycles and at 10^5..10^6 rollouts that issue
+// rate — not HBM — bounds the pass.  Here a wave owns 64 rollouts and
+// walks the horizon step by step:
+//   * every per-step operation is one instruction for 64 rollouts, no cross-lane traffic;
+//     the float cumulative sums run in the reference's own sequential order
+//     (optimizer.cpp:313-343);
+//   * everything uniform over the batch (u[t], map geometry, weights) sits in SGPRs;
+//   * noise is read from a time-major copy [T][B]: one coalesced 256-B row piece per array
+//     and step, prefetched four steps ahead;
+//   * the noised controls of the 64 rollouts stay PARKED IN REGISTERS (3 x 64 per lane)
+//     until the rollouts' costs, hence softmax weights, are known; then
+//     U[t] += sum_b w_b c[b][t] is a 64 x 64 transpose-reduce done in registers:
+//     v_permlane32_swap / v_permlane16_swap (gfx950) and bank-masked DPP adds — two
+//     instructions per butterfly node, no LDS, no second read of the noise;
+//   * the block partial {min, sum w, furthest, non-colliding, U[3T]} has the layout of the
+//     wave-per-rollout pass, so reduction, combine and the multi-GPU tuple are shared.
+//
+// Scope: the lean scoring mode (every cost_power == 1, no GoalAngle term active, no path
+// orientations, no trajectory write-out) at T <= 64; smpc_api.cpp routes every other tick
+// to smpc_pass.  Compiled with -ffp-contract=off like smpc_kernels.hip.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "smpc_dev.h"
+#include "smpc_device_math.h"
+
+#define WAVE 64
+#define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(4))) * cfloat_p;
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LANE_PARK_STRIDE 65   // floats per time step of the LDS-parked control (+1: bank skew)
+
+// ---------------------------------------------------------------------------
+// [B][T] -> [T][B] (one-off, after the noise is drawn or supplied)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) smpc_transpose_bt(const float* __restrict__ src,
+                                                        float* __restrict__ dst, uint32_t B,
+                                                        uint32_t T)
+{
+  __shared__ float tile[32][33];
+  const uint32_t bx = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+  const uint32_t lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+  for (uint32_t k = ly; k < 32; k += 8) {
+    const uint32_t b = bx + k, t = ty0 + lx;
+    tile[k][lx] = (b < B && t < T) ? src[(size_t)b * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (uint32_t k = ly; k < 32; k += 8) {
+    const uint32_t t = ty0 + k, b = bx + lx;
+    if (b < B && t < T) dst[(size_t)t * B + b] = tile[lx][k];
+  }
+}
+
+hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T,
+                                 hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_transpose_bt, dim3((B + 31) / 32, (T + 31) / 32), dim3(256), 0, st, src,
+                     dst, B, T);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// 64 x 64 transpose-reduce in registers.
+//   in : V[t] in lane b = c[b][t]      (64 registers, lane = rollout)
+//   out: lane t = sum_b w[b] * c[b][t]
+// Butterfly over the lane bits 5..0; at the node for bit k a lane keeps the register half
+// its own bit selects and receives the partner lane's copy of it, so after six levels the
+// one remaining register of lane l belongs to t = l.  Depth-first, so only ~one register
+// per level is live besides the inputs.
+// ---------------------------------------------------------------------------
+struct LaneW {      // first-level weights: {own, partner} ordered by the lane's bit 5
+  float wa, wb;
+};
+
+// a + dpp(a) everywhere, then b + dpp(b) in the banks whose lanes keep the b half
+#define SMPC_DPP_NODE(NAME, CTRL, BANKS)                                                    \
+  __device__ __forceinline__ float NAME(float a, float b)                                   \
+  {                                                                                         \
+    float t;                                                                                \
+    asm("s_nop 1\n\t"                                                              \
+                 "v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"         \
+                 "v_add_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:" BANKS          \
+                 : "=&v"(t)                                                                 \
+                 : "v"(a), "v"(b));                                                         \
+    return t;                                                                               \
+  }
+SMPC_DPP_NODE(node_bit3, "row_ror:8", "0xc")          // partner l ^ 8, b half in lanes 8..15
+SMPC_DPP_NODE(node_bit2, "row_half_mirror", "0xa")    // partner l ^ 7, b half where bit 2 is set
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+  return __uint_as_float(
+    (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+
+template <int K, int Rr>
+__device__ __forceinline__ float lane_reduce_node(const float (&V)[64], const LaneW& w, int lane)
+{
+  if constexpr (K == 0) {
+    return V[Rr];
+  } else {
+    const float a = lane_reduce_node<K - 1, Rr>(V, w, lane);
+    const float b = lane_reduce_node<K - 1, Rr + (64 >> K)>(V, w, lane);
+    if constexpr (K == 1) {
+      // lanes 32..63 of a <-> lanes 0..31 of b; then a = {a.lo, b.lo}, b = {a.hi, b.hi}
+      const u32x2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b),
+                                                       false, false);
+      return fmaf(w.wa, __uint_as_float(s.x), w.wb * __uint_as_float(s.y));
+    } else if constexpr (K == 2) {
+      // odd 16-lane rows of a <-> even rows of b
+      const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b),
+                                                       false, false);
+      return __uint_as_float(s.x) + __uint_as_float(s.y);
+    } else if constexpr (K == 3) {
+      return node_bit3(a, b);
+    } else if constexpr (K == 4) {
+      return node_bit2(a, b);
+    } else if constexpr (K == 5) {
+      const float ta = a + dpp_mov<0x4E>(a);   // quad_perm [2,3,0,1]: partner l ^ 2
+      const float tb = b + dpp_mov<0x4E>(b);
+      return (lane & 2) ? tb : ta;
+    } else {
+      const float ta = a + dpp_mov<0xB1>(a);   // quad_perm [1,0,3,2]: partner l ^ 1
+      const float tb = b + dpp_mov<0xB1>(b);
+      return (lane & 1) ? tb : ta;
+    }
+  }
+}
+
+__device__ __forceinline__ LaneW lane_weights(float w, int lane)
+{
+  const float wo = __shfl_xor(w, 32, WAVE);
+  LaneW r;
+  r.wa = lane < 32 ? w : wo;
+  r.wb = lane < 32 ? wo : w;
+  return r;
+}
+
+__device__ __forceinline__ float lane_reduce64(const float (&V)[64], const LaneW& w, int lane)
+{
+  return lane_reduce_node<6, 0>(V, w, lane);
+}
+
+// self-test of the transpose-reduce (tests/test_gpu_parity.py): v [64 lanes][64], w [64]
+__global__ void __launch_bounds__(64) smpc_lane_reduce_kernel(const float* __restrict__ v,
+                                                              const float* __restrict__ w,
+                                                              float* __restrict__ out)
+{
+  const int lane = threadIdx.x;
+  float V[64];
+#pragma unroll
+  for (int t = 0; t < 64; ++t) V[t] = v[lane * 64 + t];
+  const LaneW lw = lane_weights(w[lane], lane);
+  out[lane] = lane_reduce64(V, lw, lane);
+}
+
+hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_lane_reduce_kernel, dim3(1), dim3(64), 0, st, v, w, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Costmap2D::worldToMap + getCost, window-relative (see cost_at in smpc_device_math.h
+// for the guard-band argument; here the float origin is the LDS window's corner, so
+// the truncated quotient is the window cell itself).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int cvt_floor_i32(float q)
+{
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(q));
+  return r;
+}
+
+// The reference's own double arithmetic (nav2_costmap_2d worldToMap) for the lanes whose
+// float quotient is near a cell edge, outside the LDS window or off the map.  Returns the
+// index of the LDS byte that holds the cell's cost: a window cell, the NO_INFORMATION byte
+// behind the window (off the map, obstacles_critic.cpp:209-212), or this lane's own
+// scratch byte after fetching the cost from the global map.
+__device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s_map, float x,
+                                                    float y, uint32_t slot)
+{
+  const uint32_t nwin = (uint32_t)(p.win_w * p.win_h);
+  uint32_t mx = 0, my = 0;
+  bool on = cell_index_exact((double)x, p.ox, p.res, p.W, mx);
+  on = cell_index_exact((double)y, p.oy, p.res, p.H, my) && on;
+  if (!on) return nwin;
+  const uint32_t wx = mx - (uint32_t)p.win_x0, wy = my - (uint32_t)p.win_y0;
+  if (wx < (uint32_t)p.win_w && wy < (uint32_t)p.win_h) return wy * p.win_w + wx;
+  s_map[nwin + 1 + slot] = p.map[(size_t)my * p.W + mx];
+  return nwin + 1 + slot;
+}
+
+// ---------------------------------------------------------------------------
+// The pass
+// ---------------------------------------------------------------------------
+// FULL: T == 64, every parked register is written by every group; OBST: ObstaclesCritic scored
+template <bool FULL, bool OBST>
+__global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p, const SmpcLds L)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint8_t* s_map = smem;
+  const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
+  float* s_px = reinterpret_cast<float*>(smem + L.off_px);
+  float* s_py = reinterpret_cast<float*>(smem + L.off_py);
+  float* s_D = reinterpret_cast<float*>(smem + L.off_D);
+  uint8_t* s_valid = smem + L.off_valid;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwave = blockDim.x >> 6;
+  // per wave: [64][65] parked wz, [64] softmax weights; the head is re-used by the block combine
+  float* park = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
+  float* s_w = park + 64 * LANE_PARK_STRIDE;
+
+  // ---- stage costmap window, LUT and path into LDS -------------------------
+  if (OBST) {
+    const int ww = p.win_w, wh = p.win_h;
+    const bool vec = ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
+    if (vec) {
+      const int w4 = ww >> 2;
+      for (int i = tid; i < w4 * wh; i += blockDim.x) {
+        const int ry = i / w4, rx = i - ry * w4;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(
+          p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0);
+        reinterpret_cast<uint32_t*>(s_map)[ry * w4 + rx] = src[rx];
+      }
+    } else {
+      for (int i = tid; i < ww * wh; i += blockDim.x) {
+        const int ry = i / ww, rx = i - ry * ww;
+        s_map[i] = p.map[(size_t)(p.win_y0 + ry) * p.W + p.win_x0 + rx];
+      }
+    }
+    for (int i = tid; i < 256; i += blockDim.x)
+      const_cast<SmpcLut*>(s_lut)[i] = p.lut[i];
+    // one byte behind the window answers "off the map" (NO_INFORMATION,
+    // obstacles_critic.cpp:209-212); behind it one byte per lane of every wave for costs
+    // fetched from the global map (cells outside the window)
+    if (tid == 0) s_map[ww * wh] = 255;
+  }
+  for (uint32_t i = tid; i < p.P; i += blockDim.x) {
+    s_px[i] = p.px[i];
+    s_py[i] = p.py[i];
+    if (i + 1 < p.P) {
+      s_D[i] = p.D[i];
+      s_valid[i] = p.pvalid[i];
+    }
+  }
+  __syncthreads();
+
+  // ---- constants (wave-uniform: scalar registers) -------------------------------
+  // u and the path are inputs of the launch: read them through the constant address space,
+  // so that uniform loads stay scalar loads although the kernel also stores to global memory
+  const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
+  const cfloat_p cpx_ = (cfloat_p)(uintptr_t)p.px, cpy_ = (cfloat_p)(uintptr_t)p.py;
+  const uint32_t T = FULL ? 64u : p.T, B = p.B;
+  // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
+  // three tensors, the lane's own offset (b * 4) is the vector offset
+  const uint32_t noise_bytes = T * B * 4u;
+  const __amdgpu_buffer_rsrc_t rvx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvx), 0, noise_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvy), 0, noise_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.twz), 0, noise_bytes, 0x00020000);
+  const uint32_t row_bytes = B * 4u;
+  const float dt = p.dt, yaw0 = p.yaw0;
+  const double x0 = p.x0, y0 = p.y0;
+  uint32_t S = 0;
+  if (p.flags & SD_NEED_FURTHEST) {
+    S = p.d_furthest ? (uint32_t)(*p.d_furthest) : p.furthest_hint;
+    if (S >= p.P) S = p.P ? p.P - 1 : 0;
+  }
+  const bool pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && p.pa_active[S] && S > 0;
+  float pf_x = 0.f, pf_y = 0.f;
+  if ((p.flags & SD_PATH_FOLLOW) && p.P > 0) {
+    const uint32_t idx = p.pf_idx[S];
+    pf_x = p.px[idx];
+    pf_y = p.py[idx];
+  }
+  const uint32_t bs_iters = S > 1 ? 32u - (uint32_t)__builtin_clz(S - 1) : 0u;
+  float pa_inv_spacing = 0.f;
+  if (pa_on && S > 1 && p.D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / p.D[S - 1];
+  const bool want_local_furthest = (p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST);
+  const uint32_t step = p.step;
+  const uint32_t nquad = (T + 3u) >> 2;
+
+  // ---- per-wave running softmax state; U[ctrl][t] lives in lane t ----------------
+  float m_run = 3.0e38f, s_run = 0.f;
+  float Ux = 0.f, Uy = 0.f, Uz = 0.f;
+  uint32_t S_local = 0, n_noncoll = 0;
+
+  const uint32_t ngroups = (B + WAVE - 1) / WAVE;
+  const uint32_t gw = blockIdx.x * nwave + wave;
+  const uint32_t nW = gridDim.x * nwave;
+
+  // One group of 64 rollouts.  SAFE = false is the fast instance: sin/cos without the
+  // huge-argument branch (a divergent branch in the middle of the step would keep the
+  // scheduler from overlapping the costmap lookups with it); it only notes whether some
+  // |yaw| left the range of the fast reduction, commits nothing in that case and returns
+  // true, and the group is redone by the SAFE instance.
+  auto group_body = [&](auto safe_c, const uint32_t grp) -> bool {
+    constexpr bool SAFE = decltype(safe_c)::value;
+    const uint32_t b = grp * WAVE + lane;
+    const bool live = b < B;
+    const uint32_t bl = live ? b : B - 1;        // tail lanes shadow the last rollout
+    // parked noised controls of this group, c[ctrl][t] = P<ctrl><t / 32>[t % 32]: register
+    // tuples written through the scalar GPR index (s_set_gpr_idx) inside the rolled time loop
+    // and read with static indices by the transpose-reduce, which works in place
+    // (vx and vy: 128 registers).  wz is parked in this wave's LDS slot instead, [t][65]:
+    // the write is lane-contiguous, the transposed read (lane t, rollout b) conflict-free.
+    f32x32 Px0, Px1, Py0, Py1;
+    if (!FULL) Px0 = Px1 = Py0 = Py1 = (f32x32)(0.f);
+
+    // ================= rollout + per-step critics, lane = rollout =====================
+    float cpx = p.svx, cpy = p.svy, cpz = p.swz;   // v[:,0] = measured speed, v[:,t] = c[:,t-1]
+    float acc_yaw = 0.f, ax = 0.f, ay = 0.f;
+    float cs_prev = p.cos0, sn_prev = p.sin0;
+    float x = 0.f, y = 0.f;
+    float crit = 0.f, rep = 0.f;
+    bool collided = false, big = false;
+    float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    // PathAlign running state (path_align_critic.cpp:92-133)
+    // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
+    float traj_dist = 0.f, pa_sum = 0.f, pa_num = 0.f, sx_prev = p.x00f, sy_prev = p.y00f;
+    uint32_t path_pt = 0;
+    uint32_t next_sample = (pa_on && step) ? step : 0xffffffffu;
+
+    // one time step for the 64 rollouts of this wave; t, ux, uy, uz are wave-uniform
+    auto do_step = [&](const uint32_t t, const float ux, const float uy, const float uz,
+                       const float n0, const float n1, const float n2, float& cvx, float& cvy,
+                       float& cwz) {
+      // NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74)
+      cvx = ux + n0;
+      cvy = uy + n1;
+      cwz = uz + n2;
+      const float vx = cpx, vy = cpy, wz = cpz;
+      cpx = cvx;
+      cpy = cvy;
+      cpz = cwz;
+      // integrateStateVelocities (optimizer.cpp:313-343): sequential float cumsums
+      acc_yaw = acc_yaw + wz * dt;
+      const float yaw = acc_yaw + yaw0;
+      const float dxr = vx * cs_prev - vy * sn_prev;
+      const float dyr = vx * sn_prev + vy * cs_prev;
+      ax = ax + dxr * dt;
+      ay = ay + dyr * dt;
+      x = (float)(x0 + (double)ax);
+      y = (float)(y0 + (double)ay);
+
+      // ObstaclesCritic lookup (obstacles_critic.cpp:139-171).  Fast cell index first (see
+      // cost_at in smpc_device_math.h for the guard-band argument; the float origin is the
+      // LDS window's corner, so the truncated quotient is the window cell itself).  The
+      // rare lanes near a cell edge, outside the window or off the map get their LDS byte
+      // index from the exact path; then ONE pair of dependent LDS reads serves every lane
+      // and overlaps the sin/cos below.
+      SmpcLut e = {0.f, 0.f};
+      if (OBST) {
+        const float qx = (x - p.wxf) * p.rinvf, qy = (y - p.wyf) * p.rinvf;
+        const float rx = __builtin_amdgcn_fractf(qx), ry = __builtin_amdgcn_fractf(qy);
+        const int lx = cvt_floor_i32(qx), ly = cvt_floor_i32(qy);
+        const float lo = p.cell_eps_w, hi = 1.0f - p.cell_eps_w;
+        const bool fast = (rx >= lo) & (rx <= hi) & (ry >= lo) & (ry <= hi) &
+                          ((uint32_t)lx < (uint32_t)p.win_w) & ((uint32_t)ly < (uint32_t)p.win_h);
+        uint32_t idx = fast ? (uint32_t)(ly * p.win_w + lx) : 0u;
+        if (__builtin_expect(__any(!fast), 0)) {
+          if (!fast) idx = cell_byte_exact(p, s_map, x, y, (uint32_t)(wave * WAVE + lane));
+        }
+        e = s_lut[s_map[idx]];
+      }
+
+      // cos_[t+1] = cos(yaw[t]); the last step's is never used
+      if (SAFE) {
+        smpc_sincos(yaw, sn_prev, cs_prev);
+      } else {
+        big = big || !(fabsf(yaw) < 65536.0f);
+        smpc_sincos_fast(yaw, sn_prev, cs_prev);
+      }
+      // PreferForwardCritic (prefer_forward_critic.cpp:42-46)
+      pfw = fmaf(fmaxf(-vx, 0.f), dt, pfw);
+      // updateControlSequence gamma terms (optimizer.cpp:365-380): sum_t u (c - u)
+      gx = fmaf(ux, cvx - ux, gx);
+      gz = fmaf(uz, cwz - uz, gz);
+      gy = fmaf(uy, cvy - uy, gy);
+
+      if (OBST) {
+        // steps after the first collision are never visited in the reference: masked
+        collided = collided | (e.crit < 0.f);   // inCollision
+        crit += collided ? 0.f : e.crit;
+        rep += collided ? 0.f : e.rep;
+      }
+      // PathAlignCritic sample (uniform in t): trajectory points step, 2 step, ...
+      if (t == next_sample) {
+        next_sample += step;
+        const float ddx = x - sx_prev, ddy = y - sy_prev;
+        traj_dist += fast_sqrt(ddx * ddx + ddy * ddy);
+        sx_prev = x;
+        sy_prev = y;
+        // utils::findClosestPathPt(D, traj_dist, path_pt) (tools/utils.hpp:665-675):
+        // std::lower_bound over D[0..S) guessed from the mean spacing, confirmed against
+        // D[g-1], D[g], D[g+1]; binary search only if some lane is unconfirmed
+        const float dist = traj_dist;
+        uint32_t gi = (uint32_t)(dist * pa_inv_spacing);
+        gi = gi < S ? gi : S - 1;
+        const float da = gi > 0 ? s_D[gi - 1] : -3.0e38f;
+        const float db = s_D[gi];
+        const float dc = gi + 1 < S ? s_D[gi + 1] : 3.0e38f;
+        uint32_t lo;
+        float dl, dh;
+        const bool at_g = da < dist && !(db < dist);
+        const bool at_g1 = db < dist && !(dc < dist);
+        if (at_g) {
+          lo = gi; dl = da; dh = db;
+        } else {
+          lo = gi + 1; dl = db; dh = dc;
+        }
+        if (__builtin_expect(__any(!(at_g || at_g1)), 0)) {
+          uint32_t base = 0, nn = S;
+          for (uint32_t it = 0; it < bs_iters; ++it) {
+            const uint32_t half = nn >> 1;
+            base = (s_D[base + half - 1 + (half == 0)] < dist && half) ? base + half : base;
+            nn -= half;
+          }
+          const float d_base = s_D[base];
+          lo = base + (d_base < dist ? 1u : 0u);
+          dl = lo > 0 ? s_D[lo - 1] : 0.f;
+          dh = lo < S ? s_D[lo] : 0.f;
+        }
+        // lower_bound restricted to [path_pt, S) is the global one, since path_pt <= lo
+        uint32_t pt;
+        if (lo == path_pt) pt = 0;                 // iter == begin + init
+        else if (lo >= S) pt = S - 1;              // end(): defined as size-1
+        else pt = (dist - dl < dh - dist) ? lo - 1 : lo;
+        path_pt = pt;
+        const bool ok = s_valid[pt] != 0;
+        const float ex = s_px[pt] - x, ey = s_py[pt] - y;
+        const float d = fast_sqrt(ex * ex + ey * ey);
+        pa_num += ok ? 1.0f : 0.f;
+        pa_sum += ok ? d : 0.f;
+      }
+    };
+
+    // noise, time-major: row t is a uniform base + this lane's offset; four steps in flight.
+    // The control sequence of the next four steps is fetched (scalar loads) a quad ahead too.
+    const uint32_t loff = bl * 4u;
+    auto ld = [&](const __amdgpu_buffer_rsrc_t r, uint32_t t) -> float {
+      const uint32_t tc = (FULL || t < T) ? t : T - 1;
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, tc * row_bytes, 0));
+    };
+    auto ldu = [&](uint32_t ctrl, uint32_t t) -> float {return cu[ctrl * T + (t < T ? t : T - 1)];};
+    float nq[12], uq[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      nq[3 * i + 0] = ld(rvx, i);
+      nq[3 * i + 1] = ld(rvy, i);
+      nq[3 * i + 2] = ld(rwz, i);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) uq[3 * i + k] = ldu(k, i);
+    }
+    // four steps; returns their noised controls cq[3 i + ctrl]
+    auto run_quad = [&](const uint32_t q, float (&cq)[12]) {
+      float uc[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) uc[j] = uq[j];
+      if (q + 1 < nquad) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) uq[3 * i + k] = ldu(k, 4 * (q + 1) + i);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t t = 4 * q + i;
+        // this step's noise; its registers are refilled at once with step t + 4
+        const float n0 = nq[3 * i], n1 = nq[3 * i + 1], n2 = nq[3 * i + 2];
+        if (q + 1 < nquad) {
+          nq[3 * i + 0] = ld(rvx, t + 4);
+          nq[3 * i + 1] = ld(rvy, t + 4);
+          nq[3 * i + 2] = ld(rwz, t + 4);
+        }
+        cq[3 * i] = cq[3 * i + 1] = cq[3 * i + 2] = 0.f;
+        if (FULL || t < T)
+          do_step(t, uc[3 * i], uc[3 * i + 1], uc[3 * i + 2], n0, n1, n2, cq[3 * i], cq[3 * i + 1],
+                  cq[3 * i + 2]);
+      }
+    };
+    // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
+    const uint32_t qh = nquad < 8u ? nquad : 8u;
+    for (uint32_t q = 0; q < qh; ++q) {
+      float cq[12];
+      run_quad(q, cq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (4 * q + i) & 31u;
+        Px0[k] = cq[3 * i];
+        Py0[k] = cq[3 * i + 1];
+        park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+      }
+    }
+    for (uint32_t q = 8; q < nquad; ++q) {
+      float cq[12];
+      run_quad(q, cq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (4 * q + i) & 31u;
+        Px1[k] = cq[3 * i];
+        Py1[k] = cq[3 * i + 1];
+        park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+      }
+    }
+    if (!SAFE && __builtin_expect(__any(big), 0)) return true;
+
+    // ================= per-rollout epilogue, lane = rollout ==============================
+    // nearest path point of the endpoint (utils.hpp:292-319): first minimum wins
+    if (want_local_furthest) {
+      float best = 3.4028234663852886e38f;
+      uint32_t bi = 0;
+      for (uint32_t j = 0; j < p.P; ++j) {
+        const float ddx = cpx_[j] - x, ddy = cpy_[j] - y;
+        const float d = ddx * ddx + ddy * ddy;
+        if (d < best) {
+          best = d;
+          bi = j;
+        }
+      }
+      uint32_t m = live ? bi : 0u;
+      for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, WAVE));
+      S_local = max(S_local, m);
+    }
+    // costs (every cost_power == 1): the lean association of smpc_pass MODE 0
+    float cost = (p.flags & SD_ACCUMULATE) ? p.costs_prev[bl] : 0.f;
+    float lin = 0.f, uni = 0.f;
+    if (OBST) {
+      lin = (collided ? 0.f : p.obs_critical_w * crit) + p.obs_rep_over_T * rep;
+      uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+      n_noncoll += (uint32_t)__popcll(__ballot(live && !collided));
+    }
+    if (p.flags & SD_PATH_FOLLOW) {
+      const float fdx = x - pf_x, fdy = y - pf_y;
+      uni += p.pf_weight * fast_sqrt(fdx * fdx + fdy * fdy);
+    }
+    if (p.flags & SD_PREFER_FORWARD) lin += pfw * p.pfw_weight;
+    lin += p.g_vx * gx;
+    lin += p.g_wz * gz;
+    lin += p.g_vy * gy;
+    cost += uni + lin;
+    if (pa_on) {
+      const float c_pa = pa_num > 0.f ? pa_sum * fast_rcp(pa_num) : 0.f;
+      cost += c_pa * p.pa_weight;
+    }
+    if (live) p.costs[b] = cost;
+
+    // ---- softmax of the group (optimizer.cpp:382-391 as an online sum) --------------
+    float cmin = live ? cost : 3.0e38f;
+    for (int o = 32; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, WAVE));
+    const float m_new = fminf(m_run, cmin);
+    const float f = __builtin_amdgcn_exp2f(p.k2 * (m_run - m_new));
+    const float w = live ? __builtin_amdgcn_exp2f(p.k2 * (cost - m_new)) : 0.f;
+    float wsum = w;
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, WAVE);
+    s_run = fmaf(s_run, f, wsum);
+    m_run = m_new;
+
+    // ================= U[t] += sum_b w_b c[b][t]: transpose-reduce in registers ==========
+    const LaneW lw = lane_weights(w, lane);
+    {
+      float V[64];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        V[t] = Px0[t];
+        V[32 + t] = Px1[t];
+      }
+      Ux = fmaf(Ux, f, lane_reduce64(V, lw, lane));
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        V[t] = Py0[t];
+        V[32 + t] = Py1[t];
+      }
+      Uy = fmaf(Uy, f, lane_reduce64(V, lw, lane));
+    }
+    {
+      // wz from the LDS slot: lane t walks its row of 64 rollouts
+      s_w[lane] = w;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float* row = park + lane * LANE_PARK_STRIDE;
+      float acc = 0.f;
+#pragma unroll
+      for (int bq = 0; bq < 16; ++bq) {
+        const f32x4 wv = reinterpret_cast<const f32x4*>(s_w)[bq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(wv[e], row[4 * bq + e], acc);
+      }
+      Uz = fmaf(Uz, f, acc);
+      __builtin_amdgcn_wave_barrier();
+    }
+    return false;
+  };
+
+  for (uint32_t grp = gw; grp < ngroups; grp += nW) {
+    if (__builtin_expect(group_body(std::false_type{}, grp), 0)) group_body(std::true_type{}, grp);
+  }
+
+  // ---- block combine -> one partial per block (same tuple as the wave-per-rollout pass)
+  __syncthreads();
+  const uint32_t TL = 4 + 3 * T;
+  float* myp = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
+  if (lane == 0) {
+    myp[0] = m_run;
+    myp[1] = s_run;
+    myp[2] = (float)S_local;
+    myp[3] = (float)n_noncoll;
+  }
+  if ((uint32_t)lane < T) {
+    myp[4 + lane] = Ux;
+    myp[4 + T + lane] = Uy;
+    myp[4 + 2 * T + lane] = Uz;
+  }
+  __syncthreads();
+  const float* allp = reinterpret_cast<const float*>(smem + L.off_scr);
+  float bm = 3.0e38f;
+  for (int w = 0; w < nwave; ++w) bm = fminf(bm, allp[(size_t)w * L.scr_stride]);
+  float* outp = p.partials + (size_t)blockIdx.x * TL;
+  for (uint32_t i = tid; i < TL; i += blockDim.x) {
+    float acc = 0.f;
+    if (i == 0) {
+      acc = bm;
+    } else if (i == 2) {
+      for (int w = 0; w < nwave; ++w) acc = fmaxf(acc, allp[(size_t)w * L.scr_stride + 2]);
+    } else if (i == 3) {
+      for (int w = 0; w < nwave; ++w) acc += allp[(size_t)w * L.scr_stride + 3];
+    } else {
+      for (int w = 0; w < nwave; ++w) {
+        const float mw = allp[(size_t)w * L.scr_stride];
+        const float sc = expf(p.neg_inv_temp * (mw - bm));
+        acc += sc * allp[(size_t)w * L.scr_stride + i];
+      }
+    }
+    outp[i] = acc;
+  }
+}
+
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st)
+{
+  const bool full = p.T == 64u, obst = (p.flags & SD_OBSTACLES) != 0;
+#define SMPC_LANE_LAUNCH(F, O) \
+  hipLaunchKernelGGL((smpc_pass_lane<F, O>), dim3(grid), dim3(LANE_BLOCK), L.total, st, p, L)
+  if (full && obst) SMPC_LANE_LAUNCH(true, true);
+  else if (full) SMPC_LANE_LAUNCH(true, false);
+  else if (obst) SMPC_LANE_LAUNCH(false, true);
+  else SMPC_LANE_LAUNCH(false, false);
+#undef SMPC_LANE_LAUNCH
+  return hipGetLastError();
+}
+
+uint32_t smpc_lane_block() {return LANE_BLOCK;}
+
+static const void* lane_kernel(bool full, bool obst)
+{
+  if (full) return obst ? reinterpret_cast<const void*>(&smpc_pass_lane<true, true>)
+                        : reinterpret_cast<const void*>(&smpc_pass_lane<true, false>);
+  return obst ? reinterpret_cast<const void*>(&smpc_pass_lane<false, true>)
+              : reinterpret_cast<const void*>(&smpc_pass_lane<false, false>);
+}
+
+hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu)
+{
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lane_kernel(full, true),
+                                                      LANE_BLOCK, lds_bytes);
+}
+
+hipError_t smpc_lane_set_lds_limit(int bytes)
+{
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 4 && e == hipSuccess; ++k)
+    e = hipFuncSetAttribute(lane_kernel(k & 1, k & 2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            bytes);
+  return e;
+}

@@ -149,6 +149,14 @@ class Smpc:
         self._ck(self.lib.smpc_selftest_sincos(self.h, _ptr(x), x.size, _ptr(s), _ptr(c)))
         return s, c
 
+    def selftest_lane_reduce(self, v, w):
+        """out[t] = sum_b w[b] v[b, t] through the lane pass's in-register transpose-reduce."""
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(64, 64)
+        w = np.ascontiguousarray(w, dtype=np.float32).reshape(64)
+        out = np.empty(64, np.float32)
+        self._ck(self.lib.smpc_selftest_lane_reduce(self.h, _ptr(v), _ptr(w), _ptr(out)))
+        return out
+
     # ---- batch-sharded phases (device pointers are plain ints) ------------------
     def set_stream(self, hip_stream):
         self._ck(self.lib.smpc_set_stream(self.h, C.c_void_p(hip_stream)))
