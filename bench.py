@@ -266,7 +266,8 @@ def main():
                 "scoring_passes_per_tick": passes,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "smpc_pass<1,0>",
+                "bound": "hbm",
+                "kernel": "smpc_pass_lane<true,true>" if out.pass_kind == 1 else "smpc_pass<1,0,true>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": by,

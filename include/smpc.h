@@ -193,7 +193,9 @@ typedef struct smpc_tick_out {
   float device_ms;          /* SMPC_FLAG_PROFILE: GPU time of this call, first upload to
                                last kernel (HIP events on the ctx's stream); else 0 */
   float score_pass_ms;      /* SMPC_FLAG_PROFILE: mean GPU time of one scoring-pass
-                               kernel (smpc_pass) of this call, HIP events around it */
+                               kernel of this call, HIP events around it            */
+  uint32_t pass_kind;       /* which streaming pass scored the last iteration:
+                               0 smpc_pass (wave per rollout), 1 smpc_pass_lane     */
 } smpc_tick_out;
 
 typedef struct smpc_ctx smpc_ctx;

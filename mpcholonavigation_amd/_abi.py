@@ -154,6 +154,7 @@ class SmpcTickOut(C.Structure):
         ("passes", C.c_uint32),
         ("device_ms", C.c_float),
         ("score_pass_ms", C.c_float),
+        ("pass_kind", C.c_uint32),
     ]
 
 

@@ -52,7 +52,7 @@ thread_local std::string g_create_error;
 // threads per block of the streaming pass: 16 waves share one costmap window and produce one
 // partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
 inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
-constexpr uint32_t kLaneMinBatch = 0xffffffffu;  // lane-per-rollout pass from this batch size up
+constexpr uint32_t kLaneMinBatch = 128u * 1024u;  // lane-per-rollout pass from this batch size up (measured crossover ~100k)
 constexpr uint32_t kLaneMaxT = 64;        // it parks 3 x 64 noised controls per lane in registers
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
@@ -110,6 +110,7 @@ struct smpc_ctx {
   float* d_twz = nullptr;
   bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
+  uint32_t last_pass_kind = 0;
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
@@ -647,7 +648,9 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   if (c->lane_now && !(flags & SD_STORE_TRAJ)) {
     nblk = c->grid_tpr;
     HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->stream));
+    c->last_pass_kind = 1;
   } else {
+    c->last_pass_kind = 0;
     HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, pass_block(c->R), c->stream));
   }
   if (prof) {
@@ -1127,6 +1130,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
       if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->device_ms = ms;
     }
     out->score_pass_ms = profile_pass_ms(c);
+    out->pass_kind = c->last_pass_kind;
   }
   return SMPC_OK;
 }
@@ -1271,6 +1275,7 @@ int smpc_shard_combine(smpc_ctx* c, const float* d_tuples, uint32_t n_tuples, fl
     out->sum_w = c->h_out[3 * T + 1];
     out->passes = c->passes;
     out->score_pass_ms = profile_pass_ms(c);
+    out->pass_kind = c->last_pass_kind;
   }
   return SMPC_OK;
 }

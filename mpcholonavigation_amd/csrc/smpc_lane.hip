@@ -319,8 +319,11 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     // and read with static indices by the transpose-reduce, which works in place
     // (vx and vy: 128 registers).  wz is parked in this wave's LDS slot instead, [t][65]:
     // the write is lane-contiguous, the transposed read (lane t, rollout b) conflict-free.
-    f32x32 Px0, Px1, Py0, Py1;
-    if (!FULL) Px0 = Px1 = Py0 = Py1 = (f32x32)(0.f);
+    // Element 8 i + q' of PX<h> holds c_vx[t = 32 h + 4 q' + i]: the eight parks of a quad
+    // index with the same scalar q' (the constant 8 i folds into the base register) and can
+    // share one s_set_gpr_idx_on/off pair.
+    f32x32 PX0, PX1, PY0, PY1;
+    if (!FULL) PX0 = PX1 = PY0 = PY1 = (f32x32)(0.f);
 
     // ================= rollout + per-step critics, lane = rollout =====================
     float cpx = p.svx, cpy = p.svy, cpz = p.swz;   // v[:,0] = measured speed, v[:,t] = c[:,t-1]
@@ -328,7 +331,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     float cs_prev = p.cos0, sn_prev = p.sin0;
     float x = 0.f, y = 0.f;
     float crit = 0.f, rep = 0.f;
-    bool collided = false, big = false;
+    bool big = false;
+    float alive = 1.0f;   // 1 until the rollout's first collision, then 0 (a float mask: fma(1, a, c) == c + a)
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     // PathAlign running state (path_align_critic.cpp:92-133)
     // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
@@ -395,9 +399,9 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
 
       if (OBST) {
         // steps after the first collision are never visited in the reference: masked
-        collided = collided | (e.crit < 0.f);   // inCollision
-        crit += collided ? 0.f : e.crit;
-        rep += collided ? 0.f : e.rep;
+        alive = e.crit < 0.f ? 0.f : alive;   // inCollision
+        crit = fmaf(alive, e.crit, crit);
+        rep = fmaf(alive, e.rep, rep);
       }
       // PathAlignCritic sample (uniform in t): trajectory points step, 2 step, ...
       if (t == next_sample) {
@@ -501,9 +505,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       run_quad(q, cq);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t k = (4 * q + i) & 31u;
-        Px0[k] = cq[3 * i];
-        Py0[k] = cq[3 * i + 1];
+        PX0[8 * i + q] = cq[3 * i];
+        PY0[8 * i + q] = cq[3 * i + 1];
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
     }
@@ -512,9 +515,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       run_quad(q, cq);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t k = (4 * q + i) & 31u;
-        Px1[k] = cq[3 * i];
-        Py1[k] = cq[3 * i + 1];
+        PX1[8 * i + (q - 8)] = cq[3 * i];
+        PY1[8 * i + (q - 8)] = cq[3 * i + 1];
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
     }
@@ -526,7 +528,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       float best = 3.4028234663852886e38f;
       uint32_t bi = 0;
       for (uint32_t j = 0; j < p.P; ++j) {
-        const float ddx = cpx_[j] - x, ddy = cpy_[j] - y;
+        const float ddx = s_px[j] - x, ddy = s_py[j] - y;   // LDS broadcast reads, pipelined
         const float d = ddx * ddx + ddy * ddy;
         if (d < best) {
           best = d;
@@ -541,6 +543,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     float cost = (p.flags & SD_ACCUMULATE) ? p.costs_prev[bl] : 0.f;
     float lin = 0.f, uni = 0.f;
     if (OBST) {
+      const bool collided = alive == 0.f;
       lin = (collided ? 0.f : p.obs_critical_w * crit) + p.obs_rep_over_T * rep;
       uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
       n_noncoll += (uint32_t)__popcll(__ballot(live && !collided));
@@ -577,14 +580,14 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       float V[64];
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
-        V[t] = Px0[t];
-        V[32 + t] = Px1[t];
+        V[t] = PX0[8 * (t & 3) + (t >> 2)];
+        V[32 + t] = PX1[8 * (t & 3) + (t >> 2)];
       }
       Ux = fmaf(Ux, f, lane_reduce64(V, lw, lane));
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
-        V[t] = Py0[t];
-        V[32 + t] = Py1[t];
+        V[t] = PY0[8 * (t & 3) + (t >> 2)];
+        V[32 + t] = PY1[8 * (t & 3) + (t >> 2)];
       }
       Uy = fmaf(Uy, f, lane_reduce64(V, lw, lane));
     }

@@ -61,7 +61,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(smpc_config), sizeof(smpc_critic_params),
          sizeof(smpc_tick_in), sizeof(smpc_tick_out));
   printf("%zu %zu %zu %zu\n", offsetof(smpc_config, shard_offset), offsetof(smpc_tick_in, path_x),
-         offsetof(smpc_tick_in, fail_flag_in), offsetof(smpc_tick_out, score_pass_ms));
+         offsetof(smpc_tick_in, fail_flag_in), offsetof(smpc_tick_out, pass_kind));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -74,7 +74,7 @@ int main(void) {
     assert sizes[:4] == [C.sizeof(A.SmpcConfig), C.sizeof(A.SmpcCriticParams),
                          C.sizeof(A.SmpcTickIn), C.sizeof(A.SmpcTickOut)]
     assert sizes[4:] == [A.SmpcConfig.shard_offset.offset, A.SmpcTickIn.path_x.offset,
-                         A.SmpcTickIn.fail_flag_in.offset, A.SmpcTickOut.score_pass_ms.offset]
+                         A.SmpcTickIn.fail_flag_in.offset, A.SmpcTickOut.pass_kind.offset]
 
 
 def test_no_cpu_fallback(lib):
