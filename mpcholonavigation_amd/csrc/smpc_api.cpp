@@ -579,7 +579,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     // window + the NO_INFORMATION byte + one scratch byte per lane (cell_byte_exact)
     SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
                           window_bytes != 0, 0);
-    Lt.scr_stride = align_up(std::max(64u * 65u + 64u, 4u + 3u * T), 4);   // parked wz + weights
+    Lt.scr_stride = align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);   // parked wz + weights
     Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
     c->lds_tpr = Lt;
     if (c->occ_tpr_lds != Lt.total) {

@@ -39,7 +39,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4))) * cfloat_p;
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define LANE_PARK_STRIDE 65   // floats per time step of the LDS-parked control (+1: bank skew)
+#define LANE_PARK_STRIDE 68   // floats per time step of the LDS-parked control: 16-B aligned rows
+                              // for ds_read_b128, 4-bank skew per lane (8 lanes cover the 32 banks)
 
 // ---------------------------------------------------------------------------
 // [B][T] -> [T][B] (one-off, after the noise is drawn or supplied)
@@ -251,6 +252,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     // fetched from the global map (cells outside the window)
     if (tid == 0) s_map[ww * wh] = 255;
   }
+  for (uint32_t i = p.P + tid; i < ((p.P + 3u) & ~3u); i += blockDim.x) s_px[i] = s_py[i] = 1.0e18f;
   for (uint32_t i = tid; i < p.P; i += blockDim.x) {
     s_px[i] = p.px[i];
     s_py[i] = p.py[i];
@@ -500,6 +502,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     };
     // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
     const uint32_t qh = nquad < 8u ? nquad : 8u;
+#pragma unroll 2
     for (uint32_t q = 0; q < qh; ++q) {
       float cq[12];
       run_quad(q, cq);
@@ -510,6 +513,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
     }
+#pragma unroll 2
     for (uint32_t q = 8; q < nquad; ++q) {
       float cq[12];
       run_quad(q, cq);
@@ -527,12 +531,20 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     if (want_local_furthest) {
       float best = 3.4028234663852886e38f;
       uint32_t bi = 0;
-      for (uint32_t j = 0; j < p.P; ++j) {
-        const float ddx = s_px[j] - x, ddy = s_py[j] - y;   // LDS broadcast reads, pipelined
-        const float d = ddx * ddx + ddy * ddy;
-        if (d < best) {
-          best = d;
-          bi = j;
+      // four path points per pair of LDS broadcast reads; the arrays are padded to a
+      // multiple of four with far-away points that never win
+      const uint32_t P4 = (p.P + 3u) & ~3u;
+      for (uint32_t j = 0; j < P4; j += 4) {
+        const f32x4 qx = *reinterpret_cast<const f32x4*>(s_px + j);
+        const f32x4 qy = *reinterpret_cast<const f32x4*>(s_py + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ddx = qx[e] - x, ddy = qy[e] - y;
+          const float d = ddx * ddx + ddy * ddy;
+          if (d < best) {
+            best = d;
+            bi = j + e;
+          }
         }
       }
       uint32_t m = live ? bi : 0u;
@@ -597,15 +609,19 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const float* row = park + lane * LANE_PARK_STRIDE;
-      float acc = 0.f;
+      const f32x4* row = reinterpret_cast<const f32x4*>(park + lane * LANE_PARK_STRIDE);
+      float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-      for (int bq = 0; bq < 16; ++bq) {
-        const f32x4 wv = reinterpret_cast<const f32x4*>(s_w)[bq];
+      for (int bq = 0; bq < 16; bq += 2) {
+        const f32x4 w0 = reinterpret_cast<const f32x4*>(s_w)[bq], c0 = row[bq];
+        const f32x4 w1 = reinterpret_cast<const f32x4*>(s_w)[bq + 1], c1 = row[bq + 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = fmaf(wv[e], row[4 * bq + e], acc);
+        for (int e = 0; e < 4; ++e) {
+          acc0 = fmaf(w0[e], c0[e], acc0);
+          acc1 = fmaf(w1[e], c1[e], acc1);
+        }
       }
-      Uz = fmaf(Uz, f, acc);
+      Uz = fmaf(Uz, f, acc0 + acc1);
       __builtin_amdgcn_wave_barrier();
     }
     return false;
