@@ -209,9 +209,21 @@ def main():
     g, scn, cfg = make_ctx(B, T, MAP, shard_offset=rank * B, global_batch=world * B)
     P = len(scn.tick.path_x)
 
+    exchange_impl = "none"
     if world > 1 or force_dist:
-        from mpcholonavigation_amd.sharded import HipShard, ShardedOptimizer
-        so = ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
+        from mpcholonavigation_amd.sharded import HipShard, NativeShardedOptimizer, ShardedOptimizer
+        so = None
+        if os.environ.get("SMPC_BENCH_TORCH_EXCHANGE") != "1":
+            try:
+                # exchanges inside libsmpc: ncclAllGather on the ctx's stream between the kernels
+                so = NativeShardedOptimizer(g, speculate=not args.no_speculate)
+                exchange_impl = "RCCL called from libsmpc (smpc_shard_tick)"
+            except Exception as e:     # RCCL not loadable: same protocol through torch.distributed
+                print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed",
+                      file=sys.stderr, flush=True)
+        if so is None:
+            so = ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
+            exchange_impl = "RCCL through torch.distributed (ShardedOptimizer)"
         step_fn = so.optimize
 
         def barrier():
@@ -262,6 +274,7 @@ def main():
                 "exchange": ("none" if world == 1 else
                              ("all_reduce(max furthest) + all_gather(tuple)" if args.no_speculate else
                               "all_gather(tuple); furthest point speculated, re-scored on a miss")),
+                "exchange_impl": exchange_impl,
                 "furthest_reached_path_point": int(out.furthest_reached_path_point),
                 "scoring_passes_per_tick": passes,
             },

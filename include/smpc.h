@@ -347,6 +347,24 @@ int smpc_shard_rescore_failed(smpc_ctx* ctx, float* d_tuple);
 int smpc_shard_combine(smpc_ctx* ctx, const float* d_tuples, uint32_t n_tuples,
                        float* u_out, smpc_tick_out* out);
 
+/* ---- the same tick with the exchanges inside the library (RCCL over xGMI) ----
+ * One ncclComm per ctx, one call per tick: upload -> score -> ncclAllGather(tuples) ->
+ * combine -> wait, all on the ctx's stream (speculate != 0: the furthest point of the
+ * previous tick is used and the tick is re-scored on a miss; else an
+ * ncclAllReduce(MAX) of the furthest point precedes the scoring pass).  RCCL is
+ * resolved at run time (dlopen of librccl.so, sharing the copy the process already
+ * holds, e.g. torch.distributed's): a single-GPU user never loads it.
+ *   rank 0: smpc_shard_comm_id(id, SMPC_COMM_ID_BYTES); ship the bytes to every rank;
+ *   every rank: smpc_shard_comm_init(ctx, id, rank, world)  (collective);
+ *   per tick:   smpc_shard_tick(ctx, &in, u, &out, 1)       (collective).
+ * Replaces, for a sharded deployment, the Optimizer::optimize() call of
+ * ref src/optimizer.cpp:133-148. */
+#define SMPC_COMM_ID_BYTES 128
+int smpc_shard_comm_id(void* id_out, uint32_t id_bytes);
+int smpc_shard_comm_init(smpc_ctx* ctx, const void* id, int rank, int world);
+int smpc_shard_tick(smpc_ctx* ctx, const smpc_tick_in* in, float* u_inout, smpc_tick_out* out,
+                    int speculate);
+
 #ifdef __cplusplus
 }
 #endif

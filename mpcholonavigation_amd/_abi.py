@@ -193,7 +193,12 @@ PROTOTYPES = {
     "smpc_shard_rescore_failed": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_shard_combine": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p,
                                      C.POINTER(SmpcTickOut)]),
+    "smpc_shard_comm_id": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "smpc_shard_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "smpc_shard_tick": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p, C.POINTER(SmpcTickOut),
+                                  C.c_int]),
 }
+SMPC_COMM_ID_BYTES = 128
 
 
 def bind(lib, prototypes=None):

@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
                                                           float wz_max, float* __restrict__ u_out,
                                                           float* __restrict__ result,
                                                           const float* __restrict__ furthest_used,
-                                                          float* __restrict__ host_out)
+                                                          float* __restrict__ host_out, uint32_t seq)
 {
   const uint32_t TL = 4 + 3 * T;
   float m = 3.0e38f, fu = 0.f, nc = 0.f;
@@ -992,6 +992,14 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
       result[k] = res[k];
       if (host_out) host_out[3 * T + k] = res[k];
     }
+  }
+  // completion word for the polling host, behind every host store of this (single) block
+  if (host_out && seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(host_out + 3 * T + 7), seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1141,10 +1149,10 @@ hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
 hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, float neg_inv_temp,
                                float vx_max, float vx_min, float vy_max, float wz_max,
                                float* u_out, float* result, const float* furthest_used,
-                               float* host_out, hipStream_t st)
+                               float* host_out, uint32_t seq, hipStream_t st)
 {
   hipLaunchKernelGGL(smpc_combine_tuples, dim3(1), dim3(256), 0, st, tuples, G, T, neg_inv_temp,
-                     vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used, host_out);
+                     vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used, host_out, seq);
   return hipGetLastError();
 }
 

@@ -267,7 +267,6 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
   // u and the path are inputs of the launch: read them through the constant address space,
   // so that uniform loads stay scalar loads although the kernel also stores to global memory
   const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
-  const cfloat_p cpx_ = (cfloat_p)(uintptr_t)p.px, cpy_ = (cfloat_p)(uintptr_t)p.py;
   const uint32_t T = FULL ? 64u : p.T, B = p.B;
   // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
   // three tensors, the lane's own offset (b * 4) is the vector offset

@@ -184,6 +184,27 @@ class Smpc:
     def shard_rescore_failed(self, d_tuple):
         self._ck(self.lib.smpc_shard_rescore_failed(self.h, C.c_void_p(d_tuple)))
 
+    # ---- the sharded tick with the exchanges inside the library (RCCL) ------------
+    def shard_comm_id(self):
+        """A fresh RCCL unique id (bytes); rank 0 makes it and ships it to every rank."""
+        buf = (C.c_ubyte * A.SMPC_COMM_ID_BYTES)()
+        rc = self.lib.smpc_shard_comm_id(buf, A.SMPC_COMM_ID_BYTES)
+        if rc != 0:
+            raise SmpcError(rc, self.lib.smpc_last_error(None).decode())
+        return bytes(buf)
+
+    def shard_comm_init(self, comm_id, rank, world):
+        buf = (C.c_ubyte * A.SMPC_COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._ck(self.lib.smpc_shard_comm_init(self.h, buf, int(rank), int(world)))
+
+    def shard_tick(self, tick, u, speculate=True):
+        """One batch-sharded tick, ncclAllGather / ncclAllReduce included (collective)."""
+        u = np.ascontiguousarray(u, dtype=np.float32).copy()
+        out = A.SmpcTickOut()
+        self._ck(self.lib.smpc_shard_tick(self.h, C.byref(tick.c), _ptr(u), C.byref(out),
+                                          1 if speculate else 0))
+        return u, out
+
     def shard_combine(self, d_tuples, n_tuples):
         u = np.zeros((3, self.T), np.float32)
         out = A.SmpcTickOut()

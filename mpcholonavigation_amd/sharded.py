@@ -12,6 +12,10 @@ most two exchanges, both tiny (latency-bound, not link-bound):
      invariance (rescale by exp(-(min_g - min)/temperature)) — the reference's
      updateControlSequence (src/optimizer.cpp:382-393) on the whole batch.
 
+`NativeShardedOptimizer` runs the same protocol inside libsmpc with RCCL called from
+C++ (one library call per tick); `ShardedOptimizer` drives it phase by phase from Python
+through torch.distributed and is what the gloo CPU tests exercise.
+
 With `speculate=True` exchange 1 is skipped: each rank scores with the furthest
 point of the previous tick; the all-gathered tuples carry the true value, and on
 a miss every rank re-scores with it (exact result either way).
@@ -49,6 +53,38 @@ class HipShard:
 
     def combine(self, t_tuples, n):
         return self.smpc.shard_combine(t_tuples.data_ptr(), n)
+
+
+class NativeShardedOptimizer:
+    """The same tick with the exchanges inside libsmpc (smpc_shard_tick: ncclAllGather /
+    ncclAllReduce on the ctx's stream between the kernels; include/smpc.h).  torch.distributed
+    only ships the RCCL unique id to the ranks once.  Raises if RCCL cannot be set up; the
+    caller then falls back to ShardedOptimizer."""
+
+    def __init__(self, smpc, group=None, speculate=False):
+        self.smpc = smpc
+        self.speculate = speculate
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # every rank checks that it can load RCCL BEFORE anyone enters the collective init
+        try:
+            my_id, ok = smpc.shard_comm_id(), 1
+        except Exception:
+            my_id, ok = None, 0
+        if world > 1:
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            ok = int(t.item())
+        if not ok:
+            raise RuntimeError("RCCL is not loadable from libsmpc on every rank")
+        ids = [my_id if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=group)
+        smpc.shard_comm_init(ids[0], rank, world)
+        self.G = world
+
+    def optimize(self, tick, u):
+        return self.smpc.shard_tick(tick, u, self.speculate)
 
 
 class ShardedOptimizer:

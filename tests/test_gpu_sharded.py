@@ -96,3 +96,28 @@ def test_gpu_shard_rng_is_a_slice_of_the_global_stream():
         sh.seed(7)
         for x, y in zip(sh.get_noise(), full):
             assert np.array_equal(x, y[a:b])
+
+
+def test_native_rccl_tick_single_rank():
+    """smpc_shard_tick (RCCL called from inside libsmpc) with a one-rank communicator equals
+    the plain tick, speculating and not, over a few ticks (shift between them)."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    from tests.helpers import make_case
+    cfg, scn, noise = make_case(4096, 40)
+    ref, nat = Smpc(cfg), Smpc(cfg)
+    configure(ref, scn, noise=noise)
+    configure(nat, scn, noise=noise)
+    nat.shard_comm_init(nat.shard_comm_id(), 0, 1)
+    for speculate in (False, True):
+        u_r = u_n = scn.u0
+        for k in range(4):
+            ur, outr = ref.optimize(scn.tick, u_r)
+            un, outn = nat.shard_tick(scn.tick, u_n, speculate)
+            assert outn.fail_flag == outr.fail_flag
+            assert outn.furthest_reached_path_point == outr.furthest_reached_path_point
+            assert outn.non_colliding == outr.non_colliding
+            np.testing.assert_allclose(un, ur, rtol=2e-6, atol=2e-7)
+            u_r = np.concatenate([ur[:, 1:], ur[:, -1:]], axis=1)
+            u_n = np.concatenate([un[:, 1:], un[:, -1:]], axis=1)
+    ref.close()
+    nat.close()
