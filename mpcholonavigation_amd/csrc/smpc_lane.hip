@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
     float cs_prev = p.cos0, sn_prev = p.sin0;
     float x = 0.f, y = 0.f;
     float crit = 0.f, rep = 0.f;
-    bool big = false;
+    float yaw_max = 0.f;   // largest |yaw| seen (fast instance: range check of the sin/cos reduction)
     float alive = 1.0f;   // 1 until the rollout's first collision, then 0 (a float mask: fma(1, a, c) == c + a)
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     // PathAlign running state (path_align_critic.cpp:92-133)
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       if (SAFE) {
         smpc_sincos(yaw, sn_prev, cs_prev);
       } else {
-        big = big || !(fabsf(yaw) < 65536.0f);
+        yaw_max = fmaxf(yaw_max, fabsf(yaw));
         smpc_sincos_fast(yaw, sn_prev, cs_prev);
       }
       // PreferForwardCritic (prefer_forward_critic.cpp:42-46)
@@ -523,7 +523,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
     }
-    if (!SAFE && __builtin_expect(__any(big), 0)) return true;
+    // (a NaN yaw is sticky in the cumulative sum: the last one shows it)
+    if (!SAFE && __builtin_expect(__any(!(yaw_max < 65536.0f) || !(fabsf(acc_yaw) < 65536.0f)), 0)) return true;
 
     // ================= per-rollout epilogue, lane = rollout ==============================
     // nearest path point of the endpoint (utils.hpp:292-319): first minimum wins
@@ -536,12 +537,17 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p,
       for (uint32_t j = 0; j < P4; j += 4) {
         const f32x4 qx = *reinterpret_cast<const f32x4*>(s_px + j);
         const f32x4 qy = *reinterpret_cast<const f32x4*>(s_py + j);
+        // squared distances two at a time (packed f32), then the reference's strict "<" scan
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 xx = {x, x}, yy = {y, y};
+        const f32x2 ax0 = f32x2{qx[0], qx[1]} - xx, ay0 = f32x2{qy[0], qy[1]} - yy;
+        const f32x2 ax1 = f32x2{qx[2], qx[3]} - xx, ay1 = f32x2{qy[2], qy[3]} - yy;
+        const f32x2 d0 = ax0 * ax0 + ay0 * ay0, d1 = ax1 * ax1 + ay1 * ay1;
+        const float dd[4] = {d0[0], d0[1], d1[0], d1[1]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float ddx = qx[e] - x, ddy = qy[e] - y;
-          const float d = ddx * ddx + ddy * ddy;
-          if (d < best) {
-            best = d;
+          if (dd[e] < best) {
+            best = dd[e];
             bi = j + e;
           }
         }
