@@ -126,14 +126,13 @@ def time_config(B, T, map_size, steps, warmup):
     return r
 
 
-def cpu_baseline(T, map_size, budget_s=12.0):
+def cpu_baseline(T, map_size, budget_s=12.0, B=65536, max_ticks=200):
     """The CPU restatement built with the reference's flags, one thread
     (the reference is single-threaded: CMakeLists.txt:7-8), bounded sample."""
     from mpcholonavigation_amd.synthetic import make_noise, make_scenario
     from mpcholonavigation_amd.tick import default_config, default_critics
     from oracle.loader import Oracle, build
     build()
-    B = 65536
     cfg = default_config(batch_size=B, time_steps=T)
     scn = make_scenario(T, map_size=map_size)
     o = Oracle(cfg, fast=True)
@@ -152,7 +151,7 @@ def cpu_baseline(T, map_size, budget_s=12.0):
         u_new, _ = o.optimize(scn.tick, u)
         u = shift(u_new)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 200:
+        if time.perf_counter() - t0 > budget_s or n >= max_ticks:
             break
     el = time.perf_counter() - t0
     cpu = ""
@@ -300,6 +299,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, MAP)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            # configs[0], the reference's own CPU-runnable case (1000 x 30), on both sides
+            c0 = cpu_baseline(30, MAP, budget_s=3.0, B=1000, max_ticks=2000)
+            g0 = time_config(1000, 30, MAP, 400, 40)
+            line["cpu_baseline"]["configs[0] 1000x30"] = {
+                "cpu_rollouts_per_s": c0["value"], "cpu_ms_per_tick": 1e3 * 1000 / c0["value"],
+                "gpu_rollouts_per_s": g0["rollouts_per_s"], "gpu_ms_per_tick": g0["ms_per_tick"]}
         print(json.dumps(line), flush=True)
     g.close()
     if world > 1 or force_dist:
