@@ -151,12 +151,80 @@ typedef struct smpc_prefer_forward_params {
   float threshold_to_consider;
 } smpc_prefer_forward_params;
 
+/*
+ * The other registered critics of the holonomic stack, scored by
+ * the general streaming pass.  `enabled` defaults to 0 (not in the `critics` list).
+ * Parameter names and defaults: cost_critic.cpp:25-34, goal_critic.cpp:26-28,
+ * constraint_critic.cpp:27-38, twirling_critic.cpp:24-25, path_angle_critic.cpp:24-50,
+ * velocity_deadband_critic.cpp:24-33.
+ */
+typedef struct smpc_cost_params {
+  int32_t enabled;
+  int32_t consider_footprint; /* must be 0: point ("circular") mode only         */
+  uint32_t cost_power;
+  float cost_weight;          /* as in the YAML (3.81); divided by 254 inside    */
+  float critical_cost;
+  float collision_cost;
+  float near_goal_distance;
+} smpc_cost_params;
+
+typedef struct smpc_goal_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  float threshold_to_consider;
+} smpc_goal_params;
+
+typedef struct smpc_constraint_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  float vx_max, vy_max, vx_min; /* the controller's vx_max / vy_max / vx_min at
+                                   initialize() (constraint_critic.cpp:31-38)     */
+} smpc_constraint_params;
+
+typedef struct smpc_twirling_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+} smpc_twirling_params;
+
+typedef struct smpc_path_angle_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  uint32_t offset_from_furthest;
+  float threshold_to_consider;
+  float max_angle_to_furthest;
+  int32_t forward_preference;
+  float vx_min;                 /* the controller's vx_min: reversing allowed iff
+                                   it is negative (path_angle_critic.cpp:24-31)   */
+} smpc_path_angle_params;
+
+typedef struct smpc_velocity_deadband_params {
+  int32_t enabled;
+  uint32_t cost_power;
+  float cost_weight;
+  float deadband_velocities[3]; /* vx, vy, wz                                     */
+} smpc_velocity_deadband_params;
+
+/* Scoring order (CriticManager scores in list order and stops at the first critic that
+ * sets fail_flag, critic_manager.cpp:67-76): Constraint, Cost, Obstacles, PathAlign,
+ * PathFollow, GoalAngle, PreferForward, Goal, PathAngle, Twirling, VelocityDeadband.  A
+ * different YAML order changes float summation order (last bits) and which costs the
+ * discarded all-collide tick carries, nothing else. */
 typedef struct smpc_critic_params {
   smpc_obstacles_params obstacles;
   smpc_path_align_params path_align;
   smpc_path_follow_params path_follow;
   smpc_goal_angle_params goal_angle;
   smpc_prefer_forward_params prefer_forward;
+  smpc_cost_params cost;
+  smpc_goal_params goal;
+  smpc_constraint_params constraint;
+  smpc_twirling_params twirling;
+  smpc_path_angle_params path_angle;
+  smpc_velocity_deadband_params velocity_deadband;
 } smpc_critic_params;
 
 /*
@@ -179,6 +247,9 @@ typedef struct smpc_tick_in {
   /* 1 = CriticData::fail_flag is already set (retry after fallback():
    * CriticManager scores nothing) [ref critic_manager.cpp:70-73].            */
   int32_t fail_flag_in;
+  /* GoalChecker::getTolerances(): pose_tolerance.position.x; < 0 = no goal checker
+   * (TwirlingCritic's gate, twirling_critic.cpp:33-37, tools/utils.hpp:201-224).       */
+  float goal_checker_xy_tolerance;
 } smpc_tick_in;
 
 typedef struct smpc_tick_out {

@@ -109,6 +109,68 @@ class SmpcPreferForwardParams(C.Structure):
     ]
 
 
+class SmpcCostParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("consider_footprint", C.c_int32),
+        ("cost_power", C.c_uint32),
+        ("cost_weight", C.c_float),
+        ("critical_cost", C.c_float),
+        ("collision_cost", C.c_float),
+        ("near_goal_distance", C.c_float),
+    ]
+
+
+class SmpcGoalParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("cost_power", C.c_uint32),
+        ("cost_weight", C.c_float),
+        ("threshold_to_consider", C.c_float),
+    ]
+
+
+class SmpcConstraintParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("cost_power", C.c_uint32),
+        ("cost_weight", C.c_float),
+        ("vx_max", C.c_float),
+        ("vy_max", C.c_float),
+        ("vx_min", C.c_float),
+    ]
+
+
+class SmpcTwirlingParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("cost_power", C.c_uint32),
+        ("cost_weight", C.c_float),
+    ]
+
+
+class SmpcPathAngleParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("cost_power", C.c_uint32),
+        ("cost_weight", C.c_float),
+        ("offset_from_furthest", C.c_uint32),
+        ("threshold_to_consider", C.c_float),
+        ("max_angle_to_furthest", C.c_float),
+        ("forward_preference", C.c_int32),
+        ("vx_min", C.c_float),
+    ]
+
+
+class SmpcVelocityDeadbandParams(C.Structure):
+    _fields_ = [
+        ("enabled", C.c_int32),
+        ("cost_power", C.c_uint32),
+        ("cost_weight", C.c_float),
+        ("deadband_velocities", C.c_float * 3),
+    ]
+
+
 class SmpcCriticParams(C.Structure):
     _fields_ = [
         ("obstacles", SmpcObstaclesParams),
@@ -116,6 +178,12 @@ class SmpcCriticParams(C.Structure):
         ("path_follow", SmpcPathFollowParams),
         ("goal_angle", SmpcGoalAngleParams),
         ("prefer_forward", SmpcPreferForwardParams),
+        ("cost", SmpcCostParams),
+        ("goal", SmpcGoalParams),
+        ("constraint", SmpcConstraintParams),
+        ("twirling", SmpcTwirlingParams),
+        ("path_angle", SmpcPathAngleParams),
+        ("velocity_deadband", SmpcVelocityDeadbandParams),
     ]
 
 
@@ -140,6 +208,7 @@ class SmpcTickIn(C.Structure):
         ("goal_y", C.c_double),
         ("path_pts_valid", _u8p),
         ("fail_flag_in", C.c_int32),
+        ("goal_checker_xy_tolerance", C.c_float),
     ]
 
 

@@ -253,7 +253,7 @@ void free_ctx(smpc_ctx* c)
 
 // tick block layout (offsets in bytes), sized for the ctx's T and SMPC_MAX_PATH
 struct TickLayout {
-  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, total;
+  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, pang_active, lut_cost, total;
 };
 TickLayout tick_layout(uint32_t T, uint32_t P)
 {
@@ -267,6 +267,8 @@ TickLayout tick_layout(uint32_t T, uint32_t P)
   l.pf_idx = o; o += align_up(P * 4, 16);
   l.pvalid = o; o += align_up(P, 16);
   l.pa_active = o; o += align_up(P, 16);
+  l.pang_active = o; o += align_up(P, 16);
+  l.lut_cost = o; o += 256 * 4;   // CostCritic repulsive term per 8-bit cost
   l.total = o;
   return l;
 }
@@ -347,9 +349,9 @@ int check_tick(smpc_ctx* c, const smpc_tick_in* in)
     return fail(c, SMPC_ERR_INVALID, "path arrays missing");
   if (in->path_len > SMPC_MAX_PATH)
     return fail(c, SMPC_ERR_UNSUPPORTED, "path longer than SMPC_MAX_PATH (1024) points");
-  if (!c->map.set && (c->critics.obstacles.enabled || !in->path_pts_valid))
+  if (!c->map.set && (c->critics.obstacles.enabled || c->critics.cost.enabled || !in->path_pts_valid))
     return fail(c, SMPC_ERR_STATE, "no costmap: call smpc_set_costmap");
-  if (c->critics.obstacles.consider_footprint)
+  if (c->critics.obstacles.consider_footprint || (c->critics.cost.enabled && c->critics.cost.consider_footprint))
     return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
   return SMPC_OK;
 }
@@ -397,6 +399,25 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   if (cr.prefer_forward.enabled &&
     !within_tol(cr.prefer_forward.threshold_to_consider, rx, ry, gx, gy))
     gates |= SD_PREFER_FORWARD;                               // prefer_forward_critic.cpp:36-41
+  // the other registered critics (general pass only)
+  if (cr.constraint.enabled) gates |= SD_CONSTRAINT;
+  if (cr.cost.enabled) gates |= SD_COST;
+  if (cr.goal.enabled && within_tol(cr.goal.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_GOAL;                                         // goal_critic.cpp:38-42
+  if (cr.twirling.enabled) {
+    // utils::withinPositionGoalTolerance(goal_checker, ...) (tools/utils.hpp:201-224)
+    bool within = false;
+    if (in->goal_checker_xy_tolerance >= 0.0f) {
+      const double tol = static_cast<double>(in->goal_checker_xy_tolerance);
+      const double dx = rx - gx, dy = ry - gy;
+      within = dx * dx + dy * dy < tol * tol;
+    }
+    if (!within) gates |= SD_TWIRLING;                        // twirling_critic.cpp:33-37
+  }
+  if (cr.path_angle.enabled && P >= 1 &&
+    !within_tol(cr.path_angle.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_ANGLE;                                   // path_angle_critic.cpp:60-69
+  if (cr.velocity_deadband.enabled) gates |= SD_DEADBAND;
   if (P == 0) gates &= ~(SD_PATH_ALIGN | SD_PATH_FOLLOW);
   uint32_t nsamp = 0;
   const uint32_t step = cr.path_align.trajectory_point_step;
@@ -408,7 +429,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     if (nsamp == 0) gates &= ~SD_PATH_ALIGN;  // no samples: cost 0 for every rollout
     if (cr.path_align.use_path_orientations) gates |= SD_USE_PATH_YAW;
   }
-  if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW)) gates |= SD_NEED_FURTHEST;
+  if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW | SD_PATH_ANGLE)) gates |= SD_NEED_FURTHEST;
   if (c->map.track_unknown) gates |= SD_TRACK_UNKNOWN;
   if (c->cfg.flags & SMPC_FLAG_STORE_TRAJECTORIES) gates |= SD_STORE_TRAJ;
 
@@ -511,8 +532,57 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     memset(pf_idx, 0, std::max(P, 1u) * 4);
   }
 
+  uint8_t* pang_active = h + tl.pang_active;
+  bool pang_correct = false;
+  if (gates & SD_PATH_ANGLE) {
+    // path_angle_critic.cpp:24-31,52-54: reversing / forward preference
+    bool reversing_allowed = true;
+    if (std::fabs(cr.path_angle.vx_min) < 1e-6) reversing_allowed = false;
+    else if (cr.path_angle.vx_min < 0.0f) reversing_allowed = true;
+    bool forward_preference = cr.path_angle.forward_preference != 0;
+    if (!reversing_allowed) forward_preference = true;
+    pang_correct = reversing_allowed && !forward_preference;
+    for (uint32_t S = 0; S < P; ++S) {
+      // :73-83 utils::posePointAngle (tools/utils.hpp:417-434) against the offset point
+      const size_t idx = std::min(static_cast<size_t>(S) + cr.path_angle.offset_from_furthest,
+                                  static_cast<size_t>(P) - 1);
+      const float pose_x = static_cast<float>(rx), pose_y = static_cast<float>(ry);
+      const double point_x = px[idx], point_y = py[idx];
+      const float yaw = atan2f(static_cast<float>(point_y - static_cast<double>(pose_y)),
+                               static_cast<float>(point_x - static_cast<double>(pose_x)));
+      auto norm = [](double a) {
+        const double theta = std::fmod(a + M_PI, 2.0 * M_PI);
+        return theta <= 0.0 ? theta + M_PI : theta - M_PI;
+      };
+      const double pyaw0 = static_cast<double>(in->pose_yaw);
+      float ang = static_cast<float>(std::fabs(norm(pyaw0 - static_cast<double>(yaw))));
+      if (!forward_preference) {
+        const double b = std::fabs(norm(norm(pyaw0 + M_PI) - static_cast<double>(yaw)));
+        ang = static_cast<float>(std::min(std::fabs(norm(pyaw0 - static_cast<double>(yaw))), b));
+      }
+      pang_active[S] = ang < cr.path_angle.max_angle_to_furthest ? 0 : 1;
+    }
+  } else {
+    memset(pang_active, 0, std::max(P, 1u));
+  }
+  float* lut_cost = reinterpret_cast<float*>(h + tl.lut_cost);
+  if (gates & SD_COST) {
+    // cost_critic.cpp:120-124,141-155 per 8-bit cost (collisions are marked in the shared LUT)
+    const bool near_goal_c = within_tol(cr.cost.near_goal_distance, rx, ry, gx, gy);
+    for (int v = 0; v < 256; ++v) {
+      float t = 0.0f;
+      if (v >= 1) {
+        if (static_cast<float>(v) >= static_cast<float>(SMPC_COST_INSCRIBED)) t = cr.cost.critical_cost;
+        else if (!near_goal_c) t = static_cast<float>(v);
+      }
+      lut_cost[v] = t;
+    }
+  } else {
+    memset(lut_cost, 0, 256 * 4);
+  }
+
   // ---- Obstacles LUT: rebuilt and uploaded only when its inputs changed -----------
-  if (gates & SD_OBSTACLES) {
+  if (gates & (SD_OBSTACLES | SD_COST)) {
     const bool near_goal = within_tol(cr.obstacles.near_goal_distance, rx, ry, gx, gy);  // :124-127
     const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 1) ^ (near_goal ? 1u : 0u);
     if (!c->lut_valid || key != c->lut_key) {
@@ -572,6 +642,26 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.ga_weight = cr.goal_angle.cost_weight; d.ga_power = cr.goal_angle.cost_power;
   d.ga_goal_yaw = P ? pyaw[P - 1] : 0.f;
   d.pfw_weight = cr.prefer_forward.cost_weight; d.pfw_power = cr.prefer_forward.cost_power;
+  d.con_weight = cr.constraint.cost_weight; d.con_power = cr.constraint.cost_power;
+  {
+    // ConstraintCritic::initialize (constraint_critic.cpp:36-38)
+    const float min_sgn = cr.constraint.vx_min > 0.0f ? 1.0f : -1.0f;
+    d.con_max_vel = sqrtf(cr.constraint.vx_max * cr.constraint.vx_max + cr.constraint.vy_max * cr.constraint.vy_max);
+    d.con_min_vel = min_sgn * sqrtf(cr.constraint.vx_min * cr.constraint.vx_min + cr.constraint.vy_max * cr.constraint.vy_max);
+  }
+  d.lut_cost = reinterpret_cast<const float*>(c->d_tick + tl.lut_cost);
+  d.cost_w254 = cr.cost.cost_weight / 254.0f;   // cost_critic.cpp:34
+  d.cost_collision_cost = cr.cost.collision_cost; d.cost_power = cr.cost.cost_power;
+  d.goal_x = in->goal_x; d.goal_y = in->goal_y;
+  d.goal_weight = cr.goal.cost_weight; d.goal_power = cr.goal.cost_power;
+  d.tw_weight = cr.twirling.cost_weight; d.tw_power = cr.twirling.cost_power;
+  d.pang_active = c->d_tick + tl.pang_active;
+  d.pang_weight = cr.path_angle.cost_weight; d.pang_power = cr.path_angle.cost_power;
+  d.pang_offset = cr.path_angle.offset_from_furthest; d.pang_correct = pang_correct ? 1 : 0;
+  d.db_vx = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[0]));
+  d.db_vy = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[1]));
+  d.db_wz = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[2]));
+  d.db_weight = cr.velocity_deadband.cost_weight; d.db_power = cr.velocity_deadband.cost_power;
   d.g_vx = c->cfg.gamma / powf(c->cfg.vx_std, 2);
   d.g_vy = c->cfg.gamma / powf(c->cfg.vy_std, 2);
   d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
@@ -582,7 +672,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
 
   // ---- costmap window staged in LDS, centred on the robot ---------------------------
   uint32_t window_bytes = 0;
-  if (c->map.set && (gates & SD_OBSTACLES)) {
+  if (c->map.set && (gates & (SD_OBSTACLES | SD_COST))) {
     uint32_t side = 4;
     while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 96 cells
     const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
@@ -602,7 +692,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // persistent grid: as many blocks as stay resident, never more than the work
   const uint32_t waves_per_block = (pass_block(c->R) / 64);
   int mode_now = c->score_mode_for(cr);
-  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE)) mode_now = 2;   // lean kernel lacks these
+  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | SD_EXTRA_CRITICS)) mode_now = 2;   // lean kernels lack these
   if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
     int nb = 0;
     if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), pass_block(c->R), c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
@@ -769,6 +859,15 @@ float profile_pass_ms(smpc_ctx* c)
   return n ? sum / n : 0.f;
 }
 
+// What the reference had scored when a collision critic found every rollout colliding
+// (critic_manager.cpp:70-73 stops after it): the list of include/smpc.h up to and including
+// the first enabled collision critic — Constraint, Cost | Obstacles.
+uint32_t fail_only_flags(const smpc_ctx* c)
+{
+  const uint32_t coll = (c->gate_flags & SD_COST) ? SD_COST : SD_OBSTACLES;
+  return c->gate_flags & (SD_CONSTRAINT | coll | SD_STORE_TRAJ | SD_TRACK_UNKNOWN);
+}
+
 uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky)
 {
   // CriticManager::evalTrajectoriesScores breaks on fail_flag (critic_manager.cpp:70-73)
@@ -834,6 +933,13 @@ void smpc_critic_params_default(smpc_critic_params* p)
   p->path_follow = {1, 1, 5.0f, 1.4f, 6};
   p->goal_angle = {1, 1, 3.0f, 0.5f};
   p->prefer_forward = {1, 1, 5.0f, 0.5f};
+  // the other registered critics: initialize() defaults, not in the list (enabled 0)
+  p->cost = {0, 0, 1, 3.81f, 300.0f, 1000000.0f, 0.5f};
+  p->goal = {0, 1, 5.0f, 1.4f};
+  p->constraint = {0, 1, 4.0f, 0.5f, 0.5f, -0.35f};
+  p->twirling = {0, 1, 10.0f};
+  p->path_angle = {0, 1, 2.0f, 4, 0.5f, 1.2f, 1, -0.35f};
+  p->velocity_deadband = {0, 1, 35.0f, {0.0f, 0.0f, 0.0f}};
 }
 
 int smpc_abi_version(void) {return SMPC_ABI_VERSION;}
@@ -982,7 +1088,8 @@ int smpc_set_constraints(smpc_ctx* c, float vx_max, float vx_min, float vy_max, 
 int smpc_set_critics(smpc_ctx* c, const smpc_critic_params* p)
 {
   if (!c || !p) return SMPC_ERR_INVALID;
-  if (p->obstacles.enabled && p->obstacles.consider_footprint)
+  if ((p->obstacles.enabled && p->obstacles.consider_footprint) ||
+    (p->cost.enabled && p->cost.consider_footprint))
     return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
   c->critics = *p;
   c->critics_version++;
@@ -1118,7 +1225,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev1, c->stream));
     fetched = false;
     const bool last = it + 1 == c->cfg.iteration_count;
-    if ((flags & SD_OBSTACLES) || spec_try || last) {
+    if ((flags & (SD_OBSTACLES | SD_COST)) || spec_try || last) {
       // one host round trip: it carries fail_flag (obstacles_critic.cpp:177), the true
       // furthest point, and on the last iteration the result itself
       rc = fetch_out(c);
@@ -1143,13 +1250,13 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
         if (rc != SMPC_OK) return rc;
       }
     }
-    if ((flags & SD_OBSTACLES) && c->h_out[iNC] == 0.0f) {
+    if ((flags & (SD_OBSTACLES | SD_COST)) && c->h_out[iNC] == 0.0f) {
       // every rollout collides: the critics after Obstacles were not scored in the
       // reference (critic_manager.cpp:70-73); redo this iteration with Obstacles only
       // so that costs and u match it exactly
       fail_flag = true;
       fail_sticky = true;
-      const uint32_t only = (c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN)) |
+      const uint32_t only = fail_only_flags(c) |
         (it > 0 ? SD_ACCUMULATE : 0u);
       rc = launch_score(c, only, u_dev, nullptr, 0, c->d_tuple, true, nullptr);
       if (rc != SMPC_OK) return rc;
@@ -1301,8 +1408,7 @@ int smpc_shard_rescore_failed(smpc_ctx* c, float* d_tuple)
   if (!c || !d_tuple) return fail(c, SMPC_ERR_INVALID, "null argument");
   if (!c->tick_ready) return fail(c, SMPC_ERR_STATE, "smpc_shard_begin first");
   HIPCK(c, hipSetDevice(c->device));
-  const uint32_t only = c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN);
-  return launch_score(c, only, nullptr, nullptr, 0, d_tuple);
+  return launch_score(c, fail_only_flags(c), nullptr, nullptr, 0, d_tuple);
 }
 
 int smpc_shard_combine(smpc_ctx* c, const float* d_tuples, uint32_t n_tuples, float* u_out,
@@ -1318,7 +1424,7 @@ int smpc_shard_combine(smpc_ctx* c, const float* d_tuples, uint32_t n_tuples, fl
   memcpy(u_out, c->h_out, 3 * T * sizeof(float));
   if (out) {
     memset(out, 0, sizeof(*out));
-    const bool obstacles_scored = (scoring_flags(c, c->fail_in) & SD_OBSTACLES) != 0;
+    const bool obstacles_scored = (scoring_flags(c, c->fail_in) & (SD_OBSTACLES | SD_COST)) != 0;
     out->fail_flag = (c->fail_in || (obstacles_scored && c->h_out[3 * T + 3] == 0.0f)) ? 1 : 0;
     out->furthest_valid = (c->gate_flags & SD_NEED_FURTHEST) ? 1 : 0;
     out->furthest_reached_path_point = static_cast<uint32_t>(c->h_out[3 * T + 2]);
@@ -1431,14 +1537,13 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
       c->hint_valid = true;
     }
   }
-  const bool obstacles_scored = (flags & SD_OBSTACLES) != 0;
+  const bool obstacles_scored = (flags & (SD_OBSTACLES | SD_COST)) != 0;
   bool failed = c->fail_in;
   if (!c->fail_in && obstacles_scored && c->h_out[3 * T + 3] == 0.0f) {
     // all rollouts of the WHOLE batch collide: the reference scored nothing past Obstacles
     // (critic_manager.cpp:70-73)
     failed = true;
-    const uint32_t only = c->gate_flags & (SD_OBSTACLES | SD_STORE_TRAJ | SD_TRACK_UNKNOWN);
-    rc = launch_score(c, only, nullptr, nullptr, 0, c->d_tuple);
+    rc = launch_score(c, fail_only_flags(c), nullptr, nullptr, 0, c->d_tuple);
     if (rc == SMPC_OK) rc = gather_combine_fetch(nullptr);
     if (rc != SMPC_OK) return rc;
   }

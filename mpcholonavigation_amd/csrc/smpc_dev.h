@@ -16,6 +16,14 @@
 #define SD_TRACK_UNKNOWN 0x100u   // costmap tracks unknown space (255 is not a collision)
 #define SD_NEED_FURTHEST 0x200u   // some critic consumes furthest_reached_path_point
 #define SD_LOCAL_FURTHEST 0x400u  // the scoring pass also reports its own furthest point (speculation)
+// the other registered critics (general pass, MODE 2, only)
+#define SD_CONSTRAINT 0x800u
+#define SD_COST 0x1000u
+#define SD_GOAL 0x2000u
+#define SD_TWIRLING 0x4000u
+#define SD_PATH_ANGLE 0x8000u
+#define SD_DEADBAND 0x10000u
+#define SD_EXTRA_CRITICS (SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE | SD_DEADBAND)
 
 #define SMPC_MAX_PATH 1024        // path points staged in LDS
 #define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
@@ -84,6 +92,24 @@ struct SmpcDev {
   uint32_t ga_power;
   float pfw_weight;
   uint32_t pfw_power;
+  // the other registered critics (MODE 2)
+  float con_weight, con_max_vel, con_min_vel;   // constraint_critic.cpp:36-38
+  uint32_t con_power;
+  const float* lut_cost;                         // [256] CostCritic repulsive term per 8-bit cost
+  float cost_w254, cost_collision_cost;          // cost_weight / 254 (cost_critic.cpp:34)
+  uint32_t cost_power;
+  double goal_x, goal_y;
+  float goal_weight;
+  uint32_t goal_power;
+  float tw_weight;
+  uint32_t tw_power;
+  const uint8_t* pang_active;                    // [P] PathAngle gate per candidate furthest point
+  float pang_weight;
+  uint32_t pang_power, pang_offset;
+  int32_t pang_correct;                          // reversing allowed and no forward preference
+  double db_vx, db_vy, db_wz;                    // |deadband_velocities|
+  float db_weight;
+  uint32_t db_power;
   float g_vx, g_vy, g_wz;  // gamma / std^2 (optimizer.cpp:367-379)
   float neg_inv_temp;      // -1 / temperature (optimizer.cpp:383)
   float k2;                // neg_inv_temp * log2(e): weights as 2^(k2 (c - min))

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   float* cring = scr + L.scr_c;          // [group][3][T] parked noised controls
 
   // ---- stage costmap window, LUT and path into LDS -------------------------
-  if (!FURTHEST_ONLY && (p.flags & SD_OBSTACLES)) {
+  if (!FURTHEST_ONLY && (p.flags & (SD_OBSTACLES | SD_COST))) {
     const int ww = p.win_w, wh = p.win_h;
     const bool vec = ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
     if (vec) {
@@ -659,9 +659,28 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
     float lin = 0.f;    // MODE 0: per-lane sum of every additive per-step term
     float uni = 0.f;    // MODE 0: wave-uniform terms
 
-    // ---- ObstaclesCritic (obstacles_critic.cpp:114-178) ---------------------
-    if (p.flags & SD_OBSTACLES) {
-      float crit = 0.f, rep = 0.f;
+    // ---- ConstraintCritic (constraint_critic.cpp:41-75), holonomic branch; MODE 2 only ----
+    if (RARE && (p.flags & SD_CONSTRAINT)) {
+      double sa = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          // xt::where(vx > 0.0, 1.0, -1.0) is a double tensor: double from there on
+          const double sgn = vx[r] > 0.0f ? 1.0 : -1.0;
+          const double vel_total = sgn * (double)sqrtf(vx[r] * vx[r] + vy[r] * vy[r]);
+          const double out_max = fmax(vel_total - (double)p.con_max_vel, 0.0);
+          const double out_min = fmax((double)p.con_min_vel - vel_total, 0.0);
+          sa += (out_max + out_min) * (double)p.dt;
+        }
+      }
+      cost = add_cost_pow(cost, wave_sum_d(sa) * (double)p.con_weight, p.con_power);
+    }
+
+    // ---- costmap lookups shared by CostCritic and ObstaclesCritic ----------------
+    // (cost_critic.cpp:128-166, obstacles_critic.cpp:114-178: the same costAtPose and the same
+    // inCollision switch in point mode, so one lookup and one first-collision search)
+    if (p.flags & (SD_OBSTACLES | SD_COST)) {
+      float crit = 0.f, rep = 0.f, crep = 0.f;
       int first_r = R;  // first colliding step inside this lane
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -675,6 +694,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
           } else {
             crit += e.crit;
             rep += e.rep;
+            if (RARE && (p.flags & SD_COST)) crep += p.lut_cost[c];
           }
         }
       }
@@ -686,14 +706,22 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       } else {
         n_noncoll++;
       }
-      if (GENERIC) {
-        const float rep_sum = wave_sum(rep);
-        const float raw = collided ? p.obs_collision_cost : wave_sum(crit);
-        const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
-        cost = add_cost_pow(cost, (double)v, p.obs_power);
-      } else {
-        lin = (collided ? 0.f : obs_cw * crit) + obs_rt * rep;
-        uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+      if (RARE && (p.flags & SD_COST)) {
+        // repulsive_cost is a sum of 8-bit costs / critical_cost: exact in float in any order
+        const float repulsive = collided ? p.cost_collision_cost : wave_sum(crep);
+        const float v = p.cost_w254 * repulsive / (float)T;
+        cost = add_cost_pow(cost, (double)v, p.cost_power);
+      }
+      if (p.flags & SD_OBSTACLES) {
+        if (GENERIC) {
+          const float rep_sum = wave_sum(rep);
+          const float raw = collided ? p.obs_collision_cost : wave_sum(crit);
+          const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
+          cost = add_cost_pow(cost, (double)v, p.obs_power);
+        } else {
+          lin = (collided ? 0.f : obs_cw * crit) + obs_rt * rep;
+          uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+        }
       }
     }
 
@@ -728,6 +756,60 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       for (int r = 0; r < R; ++r) sb += fmaxf(-vx[r], 0.f) * dt;
       if (GENERIC) cost = add_cost_pow(cost, (double)(wave_sum(sb) * p.pfw_weight), p.pfw_power);
       else lin += sb * pfw_w;
+    }
+
+    // ---- GoalCritic, PathAngleCritic, TwirlingCritic, VelocityDeadbandCritic: MODE 2 only ----
+    if (RARE && (p.flags & SD_GOAL)) {
+      // goal.position is double: distances in double, xt::mean in double (goal_critic.cpp:44-54)
+      double sa = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          const double ddx = (double)x[r] - p.goal_x, ddy = (double)y[r] - p.goal_y;
+          sa += sqrt(ddx * ddx + ddy * ddy);
+        }
+      }
+      cost = add_cost_pow(cost, wave_sum_d(sa) / (double)T * (double)p.goal_weight, p.goal_power);
+    }
+    if (RARE && (p.flags & SD_PATH_ANGLE) && p.pang_active[S]) {
+      // path_angle_critic.cpp:72-100: float atan2, then the double angle arithmetic of
+      // utils::shortest_angular_distance / normalize_angles (tools/utils.hpp:258-284)
+      const uint32_t idx = min(S + p.pang_offset, p.P - 1);
+      const float tgx = s_px[idx], tgy = s_py[idx];
+      double sa = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          const float ybp = atan2f(tgy - y[r], tgx - x[r]);
+          const double d = fabs(normalize_angle((double)(ybp - yaw[r])));
+          if (p.pang_correct) {
+            const double ybp_c = d < M_PI_2 ? (double)ybp : normalize_angle((double)ybp + M_PI);
+            sa += fabs(normalize_angle(ybp_c - (double)yaw[r]));
+          } else {
+            sa += d;
+          }
+        }
+      }
+      cost = add_cost_pow(cost, wave_sum_d(sa) / (double)T * (double)p.pang_weight, p.pang_power);
+    }
+    if (RARE && (p.flags & SD_TWIRLING)) {
+      double sa = 0.0;   // twirling_critic.cpp:40-41
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) sa += (double)fabsf(wz[r]);
+      }
+      cost = add_cost_pow(cost, wave_sum_d(sa) / (double)T * (double)p.tw_weight, p.tw_power);
+    }
+    if (RARE && (p.flags & SD_DEADBAND)) {
+      double sa = 0.0;   // velocity_deadband_critic.cpp:52-76 (::fabs(double): double arithmetic)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          sa += (fmax(p.db_vx - (double)fabsf(vx[r]), 0.0) + fmax(p.db_vy - (double)fabsf(vy[r]), 0.0) +
+                 fmax(p.db_wz - (double)fabsf(wz[r]), 0.0)) * (double)p.dt;
+        }
+      }
+      cost = add_cost_pow(cost, wave_sum_d(sa) * (double)p.db_weight, p.db_power);
     }
 
     // ---- updateControlSequence gamma terms (optimizer.cpp:365-380) -----------

@@ -27,6 +27,7 @@ class Tick:
     goal_y: float
     path_pts_valid: Optional[np.ndarray] = None   # [P-1] uint8 or None (derive from costmap)
     fail_flag_in: bool = False
+    goal_checker_xy_tolerance: float = -1.0       # GoalChecker xy tolerance; < 0 = no goal checker
     _c: Optional[A.SmpcTickIn] = field(default=None, repr=False, compare=False)
 
     def __post_init__(self):
@@ -56,6 +57,7 @@ class Tick:
         if self.path_pts_valid is not None:
             t.path_pts_valid = self.path_pts_valid.ctypes.data_as(C.POINTER(C.c_uint8))
         t.fail_flag_in = int(self.fail_flag_in)
+        t.goal_checker_xy_tolerance = float(self.goal_checker_xy_tolerance)
         self._c = t
         return t
 
@@ -77,7 +79,7 @@ def default_config(**kw) -> A.SmpcConfig:
 
 
 def default_critics() -> A.SmpcCriticParams:
-    """Every critic's initialize() defaults; all five enabled."""
+    """Every critic's initialize() defaults; the north star's five enabled."""
     p = A.SmpcCriticParams()
     o = p.obstacles    # src/critics/obstacles_critic.cpp:21-31
     o.enabled, o.consider_footprint, o.cost_power = 1, 0, 1
@@ -94,4 +96,21 @@ def default_critics() -> A.SmpcCriticParams:
     g.enabled, g.cost_power, g.cost_weight, g.threshold_to_consider = 1, 1, 3.0, 0.5
     w = p.prefer_forward  # src/critics/prefer_forward_critic.cpp:20-27
     w.enabled, w.cost_power, w.cost_weight, w.threshold_to_consider = 1, 1, 5.0, 0.5
+    # the other registered critics: their initialize() defaults, not in the list (enabled 0)
+    c = p.cost         # src/critics/cost_critic.cpp:25-31
+    c.enabled, c.consider_footprint, c.cost_power, c.cost_weight = 0, 0, 1, 3.81
+    c.critical_cost, c.collision_cost, c.near_goal_distance = 300.0, 1000000.0, 0.5
+    gl = p.goal        # src/critics/goal_critic.cpp:26-28
+    gl.enabled, gl.cost_power, gl.cost_weight, gl.threshold_to_consider = 0, 1, 5.0, 1.4
+    k = p.constraint   # src/critics/constraint_critic.cpp:27-35 (parent vx_max, vy_max, vx_min)
+    k.enabled, k.cost_power, k.cost_weight = 0, 1, 4.0
+    k.vx_max, k.vy_max, k.vx_min = 0.5, 0.5, -0.35
+    tw = p.twirling    # src/critics/twirling_critic.cpp:24-25
+    tw.enabled, tw.cost_power, tw.cost_weight = 0, 1, 10.0
+    pa = p.path_angle  # src/critics/path_angle_critic.cpp:24-45
+    pa.enabled, pa.cost_power, pa.cost_weight, pa.offset_from_furthest = 0, 1, 2.0, 4
+    pa.threshold_to_consider, pa.max_angle_to_furthest = 0.5, 1.2
+    pa.forward_preference, pa.vx_min = 1, -0.35
+    vd = p.velocity_deadband  # src/critics/velocity_deadband_critic.cpp:24-33
+    vd.enabled, vd.cost_power, vd.cost_weight = 0, 1, 35.0
     return p

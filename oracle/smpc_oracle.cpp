@@ -791,18 +791,285 @@ void score_prefer_forward(smpc_oracle * o, const Tick & tk)
   }
 }
 
-// CriticManager::evalTrajectoriesScores (src/critic_manager.cpp:67-76) with the
-// critic order of SURVEY.md §8(d)
+
+// ---- the other registered critics -------------------------------
+
+// CostCritic (src/critics/cost_critic.cpp:108-168), consider_footprint = false.
+// weight_ is divided by 254 at initialize() (:34).
+void score_cost(smpc_oracle * o, const Tick & tk)
+{
+  const auto & p = o->critics.cost;
+  if (!p.enabled) {
+    return;
+  }
+  const size_t B = o->B(), T = o->T();
+  const Costmap & cm = o->costmap;
+  const float weight = p.cost_weight / 254.0f;
+  // :120-124
+  const bool near_goal = within_position_goal_tolerance(
+    p.near_goal_distance, tk.in->pose_x, tk.in->pose_y, tk.in->goal_x, tk.in->goal_y);
+  std::vector<float> repulsive_cost(B, 0.0f);
+  const size_t traj_len = T;
+  bool all_trajectories_collide = true;
+  uint32_t non_colliding = 0;
+  for (size_t i = 0; i < B; ++i) {
+    bool trajectory_collide = false;
+    for (size_t j = 0; j < traj_len; j++) {
+      // costAtPose :203-212
+      float pose_cost;
+      unsigned x_i, y_i;
+      if (!world_to_map(cm, o->tx[i * T + j], o->ty[i * T + j], x_i, y_i)) {
+        pose_cost = SMPC_COST_NO_INFORMATION;
+      } else {
+        pose_cost = static_cast<float>(get_cost(cm, x_i, y_i));
+      }
+      if (pose_cost < 1.0f) {continue;}  // in free space
+      // inCollision :175-201
+      bool collide = false;
+      switch (static_cast<unsigned char>(pose_cost)) {
+        case SMPC_COST_LETHAL:
+          collide = true;
+          break;
+        case SMPC_COST_INSCRIBED:
+          collide = p.consider_footprint ? false : true;
+          break;
+        case SMPC_COST_NO_INFORMATION:
+          collide = cm.track_unknown ? false : true;
+          break;
+      }
+      if (collide) {
+        trajectory_collide = true;
+        break;
+      }
+      // :149-155
+      if (pose_cost >= static_cast<float>(SMPC_COST_INSCRIBED)) {
+        repulsive_cost[i] += p.critical_cost;
+      } else if (!near_goal) {
+        repulsive_cost[i] += pose_cost;
+      }
+    }
+    if (!trajectory_collide) {
+      all_trajectories_collide = false;
+      non_colliding++;
+    } else {
+      repulsive_cost[i] = p.collision_cost;
+    }
+  }
+  // :165-166
+  for (size_t i = 0; i < B; ++i) {
+    const float v = weight * repulsive_cost[i] / static_cast<float>(traj_len);
+    add_cost_pow(o->costs[i], v, p.cost_power);
+  }
+  o->fail_flag = all_trajectories_collide;
+  o->non_colliding = non_colliding;
+}
+
+// GoalCritic (src/critics/goal_critic.cpp:36-55): goal.position is double, so the
+// distances are formed in double; xt::mean accumulates in double
+void score_goal(smpc_oracle * o, const Tick & tk)
+{
+  const auto & p = o->critics.goal;
+  if (!p.enabled || !within_position_goal_tolerance(
+      p.threshold_to_consider, tk.in->pose_x, tk.in->pose_y, tk.in->goal_x, tk.in->goal_y))
+  {
+    return;
+  }
+  const size_t B = o->B(), T = o->T();
+  const double goal_x = tk.in->goal_x, goal_y = tk.in->goal_y;
+  for (size_t i = 0; i < B; ++i) {
+    double s = 0.0;
+    for (size_t t = 0; t < T; ++t) {
+      const double dx = static_cast<double>(o->tx[i * T + t]) - goal_x;
+      const double dy = static_cast<double>(o->ty[i * T + t]) - goal_y;
+      s += std::sqrt(std::pow(dx, 2) + std::pow(dy, 2));
+    }
+    const double mean = s / static_cast<double>(T);
+    add_cost_pow(o->costs[i], mean * static_cast<double>(p.cost_weight), p.cost_power);
+  }
+}
+
+// ConstraintCritic (src/critics/constraint_critic.cpp:41-75), holonomic model (no
+// Ackermann term).  xt::where(vx > 0.0, 1.0, -1.0) is a double tensor: the bound
+// violations are formed in double.
+void score_constraint(smpc_oracle * o, const Tick &)
+{
+  const auto & p = o->critics.constraint;
+  if (!p.enabled) {
+    return;
+  }
+  const size_t B = o->B(), T = o->T();
+  // initialize() :36-38
+  const float min_sgn = p.vx_min > 0.0f ? 1.0f : -1.0f;
+  const float max_vel = sqrtf(p.vx_max * p.vx_max + p.vy_max * p.vy_max);
+  const float min_vel = min_sgn * sqrtf(p.vx_min * p.vx_min + p.vy_max * p.vy_max);
+  const float dt = o->cfg.model_dt;
+  for (size_t i = 0; i < B; ++i) {
+    double s = 0.0;
+    for (size_t t = 0; t < T; ++t) {
+      const float vx = o->vx[i * T + t], vy = o->vy[i * T + t];
+      const double sgn = vx > 0.0f ? 1.0 : -1.0;
+      const double vel_total = sgn * static_cast<double>(std::sqrt(vx * vx + vy * vy));
+      const double out_max = std::max(vel_total - static_cast<double>(max_vel), 0.0);
+      const double out_min = std::max(static_cast<double>(min_vel) - vel_total, 0.0);
+      s += (out_max + out_min) * static_cast<double>(dt);
+    }
+    add_cost_pow(o->costs[i], s * static_cast<double>(p.cost_weight), p.cost_power);
+  }
+}
+
+// TwirlingCritic (src/critics/twirling_critic.cpp:30-42); the gate is
+// utils::withinPositionGoalTolerance(goal_checker, ...) (tools/utils.hpp:201-224)
+void score_twirling(smpc_oracle * o, const Tick & tk)
+{
+  const auto & p = o->critics.twirling;
+  if (!p.enabled) {
+    return;
+  }
+  if (tk.in->goal_checker_xy_tolerance >= 0.0f) {
+    // pose_tolerance.position.x is a double in the message
+    const double tol = static_cast<double>(tk.in->goal_checker_xy_tolerance);
+    const double dx = tk.in->pose_x - tk.in->goal_x, dy = tk.in->pose_y - tk.in->goal_y;
+    if (dx * dx + dy * dy < tol * tol) {
+      return;
+    }
+  }
+  const size_t B = o->B(), T = o->T();
+  for (size_t i = 0; i < B; ++i) {
+    double s = 0.0;
+    for (size_t t = 0; t < T; ++t) {
+      s += static_cast<double>(std::fabs(o->wz[i * T + t]));
+    }
+    const double mean = s / static_cast<double>(T);
+    add_cost_pow(o->costs[i], mean * static_cast<double>(p.cost_weight), p.cost_power);
+  }
+}
+
+// utils::posePointAngle (tools/utils.hpp:417-434); angles::shortest_angular_distance and
+// angles::normalize_angle are ros-humble-angles (third party): normalize_angle(to - from)
+// with normalize_angle(a) = fmod(a + pi, 2 pi) folded to (-pi, pi]
+float pose_point_angle(double pose_xd, double pose_yd, float pose_yaw, double point_x,
+                       double point_y, bool forward_preference)
+{
+  const float pose_x = static_cast<float>(pose_xd), pose_y = static_cast<float>(pose_yd);
+  const float yaw = atan2f(static_cast<float>(point_y - static_cast<double>(pose_y)),
+                           static_cast<float>(point_x - static_cast<double>(pose_x)));
+  if (!forward_preference) {
+    const double a = std::fabs(normalize_angle(static_cast<double>(pose_yaw) - static_cast<double>(yaw)));
+    const double flipped = normalize_angle(static_cast<double>(pose_yaw) + M_PI);
+    const double b = std::fabs(normalize_angle(flipped - static_cast<double>(yaw)));
+    return static_cast<float>(std::min(a, b));
+  }
+  return static_cast<float>(
+    std::fabs(normalize_angle(static_cast<double>(pose_yaw) - static_cast<double>(yaw))));
+}
+
+// PathAngleCritic (src/critics/path_angle_critic.cpp:58-101)
+void score_path_angle(smpc_oracle * o, const Tick & tk)
+{
+  const auto & p = o->critics.path_angle;
+  if (!p.enabled || tk.P == 0) {
+    return;
+  }
+  if (within_position_goal_tolerance(
+      p.threshold_to_consider, tk.in->pose_x, tk.in->pose_y, tk.in->goal_x, tk.in->goal_y))
+  {
+    return;
+  }
+  // initialize() :24-31,52-54
+  bool reversing_allowed = true;
+  if (std::fabs(p.vx_min) < 1e-6) {
+    reversing_allowed = false;
+  } else if (p.vx_min < 0.0f) {
+    reversing_allowed = true;
+  }
+  bool forward_preference = p.forward_preference != 0;
+  if (!reversing_allowed) {
+    forward_preference = true;
+  }
+  set_path_furthest_if_not_set(o, tk);
+  const size_t offseted_idx = std::min(o->furthest + p.offset_from_furthest, tk.P - 1);
+  const float goal_x = tk.px[offseted_idx];
+  const float goal_y = tk.py[offseted_idx];
+  if (pose_point_angle(tk.in->pose_x, tk.in->pose_y, tk.in->pose_yaw, goal_x, goal_y,
+      forward_preference) < p.max_angle_to_furthest)
+  {
+    return;
+  }
+  const size_t B = o->B(), T = o->T();
+  const bool correct = reversing_allowed && !forward_preference;
+  for (size_t i = 0; i < B; ++i) {
+    double s = 0.0;
+    for (size_t t = 0; t < T; ++t) {
+      // float tensors: atan2 in float; shortest_angular_distance adds M_PI: double from there
+      const float ybp = std::atan2(goal_y - o->ty[i * T + t], goal_x - o->tx[i * T + t]);
+      const float yaw = o->tyaw[i * T + t];
+      const double d = std::fabs(normalize_angle(static_cast<double>(ybp - yaw)));
+      if (correct) {
+        const double ybp_c = d < M_PI_2 ? static_cast<double>(ybp) :
+          normalize_angle(static_cast<double>(ybp) + M_PI);
+        s += std::fabs(normalize_angle(ybp_c - static_cast<double>(yaw)));
+      } else {
+        s += d;
+      }
+    }
+    const double mean = s / static_cast<double>(T);
+    add_cost_pow(o->costs[i], mean * static_cast<double>(p.cost_weight), p.cost_power);
+  }
+}
+
+// VelocityDeadbandCritic (src/critics/velocity_deadband_critic.cpp:41-98), holonomic
+// branch.  The unqualified fabs(float) resolves to ::fabs(double), so
+// fabs(deadband) - xt::fabs(v) and everything after it is double arithmetic; the sum is
+// added to the float cost in double (xtensor evaluates `costs += expr` element-wise).
+void score_velocity_deadband(smpc_oracle * o, const Tick &)
+{
+  const auto & p = o->critics.velocity_deadband;
+  if (!p.enabled) {
+    return;
+  }
+  const size_t B = o->B(), T = o->T();
+  const double dt = static_cast<double>(o->cfg.model_dt);
+  const double d0 = std::fabs(static_cast<double>(p.deadband_velocities[0]));
+  const double d1 = std::fabs(static_cast<double>(p.deadband_velocities[1]));
+  const double d2 = std::fabs(static_cast<double>(p.deadband_velocities[2]));
+  for (size_t i = 0; i < B; ++i) {
+    double s = 0.0;
+    for (size_t t = 0; t < T; ++t) {
+      s += (std::max(d0 - static_cast<double>(std::fabs(o->vx[i * T + t])), 0.0) +
+        std::max(d1 - static_cast<double>(std::fabs(o->vy[i * T + t])), 0.0) +
+        std::max(d2 - static_cast<double>(std::fabs(o->wz[i * T + t])), 0.0)) * dt;
+    }
+    add_cost_pow(o->costs[i], s * static_cast<double>(p.cost_weight), p.cost_power);
+  }
+}
+
+// The scoring order of include/smpc.h; `collision_critics_only_up_to_fail`: the re-score
+// after the whole batch was found to collide scores the list up to and including the first
+// enabled collision critic (critic_manager.cpp:70-73 stops there)
+using CriticFn = void (*)(smpc_oracle *, const Tick &);
+struct CriticEntry {
+  CriticFn fn;
+  bool collision;   // sets fail_flag
+};
+const CriticEntry kCriticOrder[11] = {
+  {score_constraint, false}, {score_cost, true}, {score_obstacles, true},
+  {score_path_align, false}, {score_path_follow, false}, {score_goal_angle, false},
+  {score_prefer_forward, false}, {score_goal, false}, {score_path_angle, false},
+  {score_twirling, false}, {score_velocity_deadband, false}};
+bool collision_critic_enabled(const smpc_oracle * o, CriticFn fn)
+{
+  return (fn == score_cost && o->critics.cost.enabled) ||
+         (fn == score_obstacles && o->critics.obstacles.enabled);
+}
+
+// CriticManager::evalTrajectoriesScores (src/critic_manager.cpp:67-76)
 void eval_trajectories_scores(smpc_oracle * o, const Tick & tk)
 {
-  using Fn = void (*)(smpc_oracle *, const Tick &);
-  const Fn critics[5] = {score_obstacles, score_path_align, score_path_follow, score_goal_angle,
-    score_prefer_forward};
-  for (size_t q = 0; q < 5; q++) {
+  for (const CriticEntry & e : kCriticOrder) {
     if (o->fail_flag) {
       break;
     }
-    critics[q](o, tk);
+    e.fn(o, tk);
   }
 }
 
@@ -1165,13 +1432,12 @@ static int shard_score_impl(smpc_oracle * o, const smpc_tick_in * in, const floa
   // short-circuit its later critics, so score obstacles and clear the flag.
   const bool fail_in = o->fail_flag;
   if (!fail_in) {
-    score_obstacles(o, tk);
-    o->fail_flag = false;
-    if (!obstacles_only) {
-      score_path_align(o, tk);
-      score_path_follow(o, tk);
-      score_goal_angle(o, tk);
-      score_prefer_forward(o, tk);
+    for (const CriticEntry & e : kCriticOrder) {
+      e.fn(o, tk);
+      o->fail_flag = false;
+      if (obstacles_only && collision_critic_enabled(o, e.fn)) {
+        break;   // the critic that stopped the manager: nothing after it was scored
+      }
     }
   }
   add_gamma_terms(o, u_in);
@@ -1315,7 +1581,9 @@ int smpc_oracle_score_critic(smpc_oracle * o, int critic_id, const smpc_tick_in 
                              int32_t * fail_flag_out)
 {
   if (!o || !in || !costs_inout) {return SMPC_ERR_INVALID;}
-  if (critic_id == SMPC_ORACLE_CRITIC_OBSTACLES && !o->costmap.set) {
+  if ((critic_id == SMPC_ORACLE_CRITIC_OBSTACLES || critic_id == SMPC_ORACLE_CRITIC_COST) &&
+    !o->costmap.set)
+  {
     return fail(o, SMPC_ERR_STATE, "no costmap");
   }
   if (furthest_preset >= 0 && in->path_len > 0 &&
@@ -1337,6 +1605,12 @@ int smpc_oracle_score_critic(smpc_oracle * o, int critic_id, const smpc_tick_in 
     case SMPC_ORACLE_CRITIC_PATH_FOLLOW: score_path_follow(o, tk); break;
     case SMPC_ORACLE_CRITIC_GOAL_ANGLE: score_goal_angle(o, tk); break;
     case SMPC_ORACLE_CRITIC_PREFER_FORWARD: score_prefer_forward(o, tk); break;
+    case SMPC_ORACLE_CRITIC_COST: score_cost(o, tk); break;
+    case SMPC_ORACLE_CRITIC_GOAL: score_goal(o, tk); break;
+    case SMPC_ORACLE_CRITIC_CONSTRAINT: score_constraint(o, tk); break;
+    case SMPC_ORACLE_CRITIC_TWIRLING: score_twirling(o, tk); break;
+    case SMPC_ORACLE_CRITIC_PATH_ANGLE: score_path_angle(o, tk); break;
+    case SMPC_ORACLE_CRITIC_VELOCITY_DEADBAND: score_velocity_deadband(o, tk); break;
     default: return fail(o, SMPC_ERR_INVALID, "unknown critic id");
   }
   memcpy(costs_inout, o->costs.data(), B * sizeof(float));
@@ -1485,6 +1759,13 @@ void smpc_critic_params_default(smpc_critic_params * p)
   p->path_follow = {1, 1, 5.0f, 1.4f, 6};                             // path_follow_critic.cpp:23-33
   p->goal_angle = {1, 1, 3.0f, 0.5f};                                 // goal_angle_critic.cpp:20-27
   p->prefer_forward = {1, 1, 5.0f, 0.5f};                             // prefer_forward_critic.cpp:20-27
+  // not in the north star's critic list: off unless asked for
+  p->cost = {0, 0, 1, 3.81f, 300.0f, 1000000.0f, 0.5f};               // cost_critic.cpp:25-31
+  p->goal = {0, 1, 5.0f, 1.4f};                                       // goal_critic.cpp:26-28
+  p->constraint = {0, 1, 4.0f, 0.5f, 0.5f, -0.35f};                   // constraint_critic.cpp:27-35
+  p->twirling = {0, 1, 10.0f};                                        // twirling_critic.cpp:24-25
+  p->path_angle = {0, 1, 2.0f, 4, 0.5f, 1.2f, 1, -0.35f};             // path_angle_critic.cpp:24-45
+  p->velocity_deadband = {0, 1, 35.0f, {0.0f, 0.0f, 0.0f}};           // velocity_deadband_critic.cpp:24-33
 }
 
 }  // extern "C"

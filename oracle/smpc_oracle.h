@@ -25,6 +25,12 @@ typedef struct smpc_oracle smpc_oracle;
 #define SMPC_ORACLE_CRITIC_PATH_FOLLOW 2
 #define SMPC_ORACLE_CRITIC_GOAL_ANGLE 3
 #define SMPC_ORACLE_CRITIC_PREFER_FORWARD 4
+#define SMPC_ORACLE_CRITIC_COST 5
+#define SMPC_ORACLE_CRITIC_GOAL 6
+#define SMPC_ORACLE_CRITIC_CONSTRAINT 7
+#define SMPC_ORACLE_CRITIC_TWIRLING 8
+#define SMPC_ORACLE_CRITIC_PATH_ANGLE 9
+#define SMPC_ORACLE_CRITIC_VELOCITY_DEADBAND 10
 
 int smpc_oracle_create(const smpc_config* cfg, smpc_oracle** out);
 void smpc_oracle_destroy(smpc_oracle* o);

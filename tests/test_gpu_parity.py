@@ -356,3 +356,47 @@ def test_lane_per_rollout_pass_parity(Smpc, Oracle, B, T, M):
         assert og.non_colliding == oo.non_colliding
         assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1,
                       label=f"lane pass {B}x{T} near={near}")
+
+
+def _extra_critics(names, power=1, **over):
+    cr = default_critics()
+    for n in ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward", "cost", "goal",
+              "constraint", "twirling", "path_angle", "velocity_deadband"):
+        sub = getattr(cr, n)
+        sub.enabled = 1 if n in names else 0
+        sub.cost_power = power
+    for k in range(3):
+        cr.velocity_deadband.deadband_velocities[k] = 0.08
+    cr.constraint.vx_max, cr.constraint.vy_max, cr.constraint.vx_min = 0.35, 0.2, -0.1
+    for path, v in over.items():
+        sub, field = path.split("__")
+        setattr(getattr(cr, sub), field, v)
+    return cr
+
+
+DEPLOYED = ("constraint", "cost", "goal", "goal_angle", "path_align", "path_follow", "path_angle",
+            "prefer_forward", "twirling")      # robot_bringup/config/nav2_params.yaml:222
+ALL11 = DEPLOYED + ("obstacles", "velocity_deadband")
+
+
+@pytest.mark.parametrize("names,power,near,B,T", [
+    (DEPLOYED, 1, False, 2000, 56), (DEPLOYED, 1, True, 2000, 56), (ALL11, 1, False, 3000, 64),
+    (ALL11, 2, False, 1500, 40), (ALL11, 1, True, 1000, 100), (("cost",), 1, False, 4096, 64),
+    (("constraint", "velocity_deadband", "twirling"), 3, False, 1000, 30),
+    (("path_angle", "goal", "cost"), 1, False, 200000, 64)])
+def test_other_registered_critics_parity(Smpc, Oracle, names, power, near, B, T):
+    """The six critics beyond the north star's five, alone and mixed with
+    them, cruise and near-goal, cost_power 1..3, against the oracle (whose restatement of each
+    is pinned by the reference's critics_tests.cpp KATs in test_oracle_reference_kats.py)."""
+    cfg, scn, noise = make_case(B, T, near_goal=near)
+    # a robot heading away from the path so that PathAngle's gate opens, reversing allowed
+    cr = _extra_critics(names, power, path_angle__max_angle_to_furthest=0.05,
+                        path_angle__forward_preference=0 if power == 2 else 1)
+    tick = scn.tick
+    tick.goal_checker_xy_tolerance = 0.25
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, critics=cr, tick=tick)
+    assert og.fail_flag == oo.fail_flag
+    assert og.non_colliding == oo.non_colliding
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
+                  label=f"critics {names} power {power} near {near}")
+    assert og.pass_kind == 0       # the general wave-per-rollout pass scores these
