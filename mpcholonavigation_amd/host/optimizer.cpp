@@ -79,6 +79,8 @@ void Optimizer::initialize(
   auto & p = critics_.params;
   p.obstacles.enabled = p.path_align.enabled = p.path_follow.enabled = 0;
   p.goal_angle.enabled = p.prefer_forward.enabled = 0;
+  p.cost.enabled = p.goal.enabled = p.constraint.enabled = p.twirling.enabled = 0;
+  p.path_angle.enabled = p.velocity_deadband.enabled = 0;
   for (const auto & name : critics_.critics) {
     if (name == "ObstaclesCritic") {
       p.obstacles.enabled = 1;
@@ -90,10 +92,21 @@ void Optimizer::initialize(
       p.goal_angle.enabled = 1;
     } else if (name == "PreferForwardCritic") {
       p.prefer_forward.enabled = 1;
+    } else if (name == "CostCritic") {
+      p.cost.enabled = 1;
+    } else if (name == "GoalCritic") {
+      p.goal.enabled = 1;
+    } else if (name == "ConstraintCritic") {
+      p.constraint.enabled = 1;
+    } else if (name == "TwirlingCritic") {
+      p.twirling.enabled = 1;
+    } else if (name == "PathAngleCritic") {
+      p.path_angle.enabled = 1;
+    } else if (name == "VelocityDeadbandCritic") {
+      p.velocity_deadband.enabled = 1;
     } else {
       throw std::runtime_error(
-              "Critic sortham::critics::" + name +
-              " is registered but not fused on the MI355X path (SURVEY.md §8(f) rank 1)");
+              "Critic sortham::critics::" + name + " is registered but not fused on the MI355X path");
     }
   }
 
@@ -189,6 +202,7 @@ void Optimizer::optimize()
   in.goal_y = goal_.y;
   in.path_pts_valid = nullptr;
   in.fail_flag_in = fail_flag_ ? 1 : 0;   // sticky across the retry (critic_manager.cpp:70-73)
+  in.goal_checker_xy_tolerance = goal_checker_xy_tolerance_;
 
   const unsigned int T = settings_.time_steps;
   std::vector<float> u(3 * T);
@@ -223,8 +237,9 @@ bool Optimizer::fallback(bool fail)
 
 Twist2D Optimizer::evalControl(
   const Pose2D & robot_pose, const Twist2D & robot_speed, const models::Path & plan,
-  const Pose2D & goal)
+  const Pose2D & goal, float goal_checker_xy_tolerance)
 {
+  goal_checker_xy_tolerance_ = goal_checker_xy_tolerance;
   prepare(robot_pose, robot_speed, plan, goal);
   do {
     optimize();

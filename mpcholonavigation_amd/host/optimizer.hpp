@@ -138,9 +138,11 @@ public:
   void setNoise(const float * nvx, const float * nvy, const float * nwz);
 
   // ref :134-155; throws std::runtime_error exactly where the reference does
+  // goal_checker_xy_tolerance: GoalChecker::getTolerances()'s pose_tolerance.position.x, < 0
+  // when the controller server passes no goal checker (TwirlingCritic's gate)
   Twist2D evalControl(
     const Pose2D & robot_pose, const Twist2D & robot_speed, const models::Path & plan,
-    const Pose2D & goal);
+    const Pose2D & goal, float goal_checker_xy_tolerance = -1.0f);
 
   void setSpeedLimit(double speed_limit, bool percentage);  // ref :428-453
   void reset();                                             // ref :116-132
@@ -181,6 +183,7 @@ protected:
   Twist2D speed_{};
   models::Path path_{};
   bool fail_flag_{false};
+  float goal_checker_xy_tolerance_{-1.0f};
   size_t retry_counter_{0};
   smpc_tick_out last_out_{};
 };

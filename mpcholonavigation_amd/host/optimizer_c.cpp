@@ -132,7 +132,8 @@ int sortham_optimizer_eval_control(
       plan.x.assign(in->path_x, in->path_x + in->path_len);
       plan.y.assign(in->path_y, in->path_y + in->path_len);
       plan.yaws.assign(in->path_yaw, in->path_yaw + in->path_len);
-      const sortham_ns::Twist2D t = o->opt.evalControl(pose, speed, plan, goal);
+      const sortham_ns::Twist2D t =
+        o->opt.evalControl(pose, speed, plan, goal, in->goal_checker_xy_tolerance);
       twist_out[0] = t.vx;
       twist_out[1] = t.vy;
       twist_out[2] = t.wz;

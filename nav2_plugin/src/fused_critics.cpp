@@ -3,13 +3,14 @@
 // critic_function.hpp, pluginlib, nav2_costmap_2d); NOT built by this repository's
 // tests — see INTEGRATION.md.
 //
-// The five critics on the MI355X path read exactly the parameters their reference
+// The eleven critics on the MI355X path read exactly the parameters their reference
 // initialize() reads (same names, same defaults) and publish them to
 // FusedCriticRegistry; score() does nothing because libsmpc scores inside the
-// fused kernel.  The other seven stay loadable but refuse to be configured, so a
-// YAML that lists them fails loudly instead of silently dropping a cost term.
+// fused kernel.  PathAlignLegacyCritic stays loadable but refuses to be configured, so a
+// YAML that lists it fails loudly instead of silently dropping a cost term.
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "nav2_sortham_controller/critic_function.hpp"   // from the reference package
 #include "nav2_sortham_controller/fused_critic_registry.hpp"
@@ -99,6 +100,76 @@ getParam(p.cost_weight, "cost_weight", 5.0);
 getParam(p.threshold_to_consider, "threshold_to_consider", 0.5);
 FUSED_CRITIC_END
 
+FUSED_CRITIC_BEGIN(CostCritic)   // ref src/critics/cost_critic.cpp:25-34
+auto & p = e.params.cost;
+bool consider_footprint = false;
+p.enabled = enabled_;
+getParam(consider_footprint, "consider_footprint", false);
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 3.81);   // libsmpc divides by 254 like :34
+getParam(p.critical_cost, "critical_cost", 300.0);
+getParam(p.collision_cost, "collision_cost", 1000000.0);
+getParam(p.near_goal_distance, "near_goal_distance", 0.5);
+p.consider_footprint = consider_footprint;
+if (consider_footprint) {
+  throw std::runtime_error(
+          "CostCritic: consider_footprint=true is not on the MI355X path yet");
+}
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(GoalCritic)   // ref src/critics/goal_critic.cpp:26-28
+auto & p = e.params.goal;
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 5.0);
+getParam(p.threshold_to_consider, "threshold_to_consider", 1.4);
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(ConstraintCritic)   // ref src/critics/constraint_critic.cpp:27-38
+auto & p = e.params.constraint;
+auto getParentParam = parameters_handler_->getParamGetter(parent_name_);
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 4.0);
+getParentParam(p.vx_max, "vx_max", 0.5);
+getParentParam(p.vy_max, "vy_max", 0.0);
+getParentParam(p.vx_min, "vx_min", -0.35);
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(TwirlingCritic)   // ref src/critics/twirling_critic.cpp:24-25
+auto & p = e.params.twirling;
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 10.0);
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(PathAngleCritic)   // ref src/critics/path_angle_critic.cpp:24-45
+auto & p = e.params.path_angle;
+auto getParentParam = parameters_handler_->getParamGetter(parent_name_);
+bool forward_preference = true;
+p.enabled = enabled_;
+getParentParam(p.vx_min, "vx_min", -0.35);
+getParam(p.offset_from_furthest, "offset_from_furthest", 4);
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 2.0);
+getParam(p.threshold_to_consider, "threshold_to_consider", 0.5);
+getParam(p.max_angle_to_furthest, "max_angle_to_furthest", 1.2);
+getParam(forward_preference, "forward_preference", true);
+p.forward_preference = forward_preference;
+FUSED_CRITIC_END
+
+FUSED_CRITIC_BEGIN(VelocityDeadbandCritic)   // ref src/critics/velocity_deadband_critic.cpp:24-33
+auto & p = e.params.velocity_deadband;
+std::vector<double> deadband{0.0, 0.0, 0.0};
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 35.0);
+getParam(deadband, "deadband_velocities", std::vector<double>{0.0, 0.0, 0.0});
+for (size_t k = 0; k < 3 && k < deadband.size(); ++k) {
+  p.deadband_velocities[k] = static_cast<float>(deadband[k]);
+}
+FUSED_CRITIC_END
+
 #define UNFUSED_CRITIC(Class)                                                                  \
   class Class : public CriticFunction                                                          \
   {                                                                                            \
@@ -107,17 +178,11 @@ public:                                                                         
     void initialize() override                                                                 \
     {                                                                                          \
       throw std::runtime_error(                                                                \
-              #Class " is registered but not fused on the MI355X path (SURVEY.md §8(f) rank 1)"); \
+              #Class " is registered but not fused on the MI355X path"); \
     }                                                                                          \
   };
 
-UNFUSED_CRITIC(CostCritic)
-UNFUSED_CRITIC(GoalCritic)
 UNFUSED_CRITIC(PathAlignLegacyCritic)
-UNFUSED_CRITIC(PathAngleCritic)
-UNFUSED_CRITIC(TwirlingCritic)
-UNFUSED_CRITIC(ConstraintCritic)
-UNFUSED_CRITIC(VelocityDeadbandCritic)
 
 }  // namespace sortham::critics
 

@@ -100,9 +100,18 @@ void Optimizer::uploadCostmap()
 geometry_msgs::msg::TwistStamped Optimizer::evalControl(
   const geometry_msgs::msg::PoseStamped & robot_pose, const geometry_msgs::msg::Twist & robot_speed,
   const nav_msgs::msg::Path & plan, const geometry_msgs::msg::Pose & goal,
-  nav2_core::GoalChecker * /*goal_checker*/)
+  nav2_core::GoalChecker * goal_checker)
 {
   uploadCostmap();
+  // utils::withinPositionGoalTolerance(goal_checker, ...) (tools/utils.hpp:201-224) needs only
+  // the checker's xy tolerance: TwirlingCritic's gate
+  float goal_checker_xy_tolerance = -1.0f;
+  if (goal_checker) {
+    geometry_msgs::msg::Pose pose_tolerance;
+    geometry_msgs::msg::Twist velocity_tolerance;
+    goal_checker->getTolerances(pose_tolerance, velocity_tolerance);
+    goal_checker_xy_tolerance = static_cast<float>(pose_tolerance.position.x);
+  }
   sortham_host::Pose2D pose{robot_pose.pose.position.x, robot_pose.pose.position.y,
     tf2::getYaw(robot_pose.pose.orientation)};
   sortham_host::Pose2D g{goal.position.x, goal.position.y, tf2::getYaw(goal.orientation)};
@@ -117,7 +126,8 @@ geometry_msgs::msg::TwistStamped Optimizer::evalControl(
     path.y[i] = plan.poses[i].pose.position.y;
     path.yaws[i] = tf2::getYaw(plan.poses[i].pose.orientation);
   }
-  const sortham_host::Twist2D t = host_.evalControl(pose, speed, path, g);   // may throw
+  const sortham_host::Twist2D t =
+    host_.evalControl(pose, speed, path, g, goal_checker_xy_tolerance);   // may throw
   geometry_msgs::msg::TwistStamped twist;   // utils::toTwistStamped (tools/utils.hpp:145-173)
   twist.header.frame_id = costmap_ros_->getBaseFrameID();
   twist.header.stamp = plan.header.stamp;

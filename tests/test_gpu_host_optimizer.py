@@ -45,6 +45,44 @@ def test_closed_loop_eval_control_matches_reference_host_logic():
     assert rel_err(h.get_optimized_trajectory(), o.get_optimized_trajectory()) < 1e-5
 
 
+def test_closed_loop_with_the_deployed_critic_list():
+    """robot_bringup/config/nav2_params.yaml:186-275: B 2000, T 56, the nine critics of its
+    `critics:` list with its weights (CostCritic in point mode: consider_footprint is out of
+    scope), closed loop against the reference host logic on the oracle."""
+    from mpcholonavigation_amd.host_optimizer import Optimizer
+    from oracle.loader import OracleOptimizer
+    names = ["ConstraintCritic", "CostCritic", "GoalCritic", "GoalAngleCritic", "PathAlignCritic",
+             "PathFollowCritic", "PathAngleCritic", "PreferForwardCritic", "TwirlingCritic"]
+    cfg = default_config(batch_size=2000, time_steps=56, vx_min=-0.5, wz_max=1.0, wz_std=0.2)
+    cr = default_critics()
+    cr.obstacles.enabled = 0
+    for n in ("constraint", "cost", "goal", "goal_angle", "path_align", "path_follow", "path_angle",
+              "prefer_forward", "twirling"):
+        getattr(cr, n).enabled = 1
+    cr.cost.near_goal_distance = 1.0
+    cr.path_align.cost_weight, cr.path_align.max_path_occupancy_ratio = 14.0, 0.05
+    cr.path_follow.offset_from_furthest = 5
+    cr.constraint.vx_max, cr.constraint.vy_max, cr.constraint.vx_min = 0.5, 0.5, -0.5
+    cr.path_angle.vx_min = -0.5
+    scn = make_scenario(56)
+    noise = make_noise(2000, 56, std=(0.2, 0.2, 0.2))
+    h = Optimizer(cfg, cr, 20.0, critics=names)
+    o = OracleOptimizer(cfg, cr, 20.0)
+    for x in (h, o):
+        x.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
+        x.set_noise(*noise)
+    t = scn.tick
+    for k in range(8):
+        tick = Tick(t.pose_x + 0.015 * k, t.pose_y, t.pose_yaw + 0.8, (0.3, 0.0, 0.0), t.path_x, t.path_y,
+                    t.path_yaw, t.goal_x, t.goal_y, goal_checker_xy_tolerance=0.25)
+        tw_h, out_h = h.eval_control(tick)
+        tw_o, out_o = o.eval_control(tick)
+        assert out_h.fail_flag == out_o.fail_flag == 0
+        assert out_h.furthest_reached_path_point == out_o.furthest_reached_path_point
+        assert rel_err(tw_h, tw_o) < 2e-4, (k, tw_h, tw_o)
+        o.set_control_sequence(h.get_control_sequence())
+
+
 def test_twist_offset_without_shifting():
     """controller period < model_dt: no shifting, Twist is element 0 (optimizer.cpp:399)."""
     h, o, scn = _pair(1000, 30, freq=30.0)

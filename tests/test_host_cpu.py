@@ -53,9 +53,9 @@ def test_configuration_errors_match_reference_messages(host):
     with pytest.raises(RuntimeError, match="only Omni"):
         host.Optimizer(cfg, cr, controller_frequency=20.0, motion_model="DiffDrive")
     # a registered critic that is not fused must not be silently dropped
-    with pytest.raises(RuntimeError, match="TwirlingCritic"):
+    with pytest.raises(RuntimeError, match="PathAlignLegacyCritic"):
         host.Optimizer(cfg, cr, controller_frequency=20.0,
-                       critics=["ObstaclesCritic", "TwirlingCritic"])
+                       critics=["ObstaclesCritic", "PathAlignLegacyCritic"])
 
 
 def test_host_needs_a_gpu(host):

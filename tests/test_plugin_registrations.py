@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CRITICS = ["ObstaclesCritic", "CostCritic", "GoalCritic", "GoalAngleCritic", "PathAlignCritic",
            "PathAlignLegacyCritic", "PathAngleCritic", "PathFollowCritic", "PreferForwardCritic",
            "TwirlingCritic", "ConstraintCritic", "VelocityDeadbandCritic"]
-FUSED = ["ObstaclesCritic", "PathAlignCritic", "PathFollowCritic", "GoalAngleCritic",
-         "PreferForwardCritic"]
+FUSED = {"ObstaclesCritic", "PathAlignCritic", "PathFollowCritic", "GoalAngleCritic", "PreferForwardCritic",
+         "CostCritic", "GoalCritic", "ConstraintCritic", "TwirlingCritic", "PathAngleCritic",
+         "VelocityDeadbandCritic"}
 
 
 def test_controller_registration():
