@@ -126,6 +126,40 @@ def time_config(B, T, map_size, steps, warmup):
     return r
 
 
+def time_multi_query(n_ctx, B, T, map_size, steps, warmup):
+    """BASELINE configs[4] per GPU: n_ctx independent planning instances (replicas only: no
+    collective), one smpc_ctx, host thread and stream each, ticking concurrently."""
+    import threading
+    ctxs = [make_ctx(B, T, map_size, seed=1234 + i) for i in range(n_ctx)]
+    start, done = threading.Barrier(n_ctx + 1), threading.Barrier(n_ctx + 1)
+
+    def worker(g, scn):
+        u = scn.u0
+        for _ in range(warmup):
+            u_new, _ = g.optimize(scn.tick, u)
+            u = shift(u_new)
+        start.wait()
+        for _ in range(steps):
+            u_new, _ = g.optimize(scn.tick, u)
+            u = shift(u_new)
+        done.wait()
+
+    ths = [threading.Thread(target=worker, args=(g, scn)) for g, scn, _ in ctxs]
+    for t in ths:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    done.wait()
+    el = time.perf_counter() - t0
+    for t in ths:
+        t.join()
+    for g, _, _ in ctxs:
+        g.close()
+    return {"queries": n_ctx, "rollouts_per_query": B, "rollouts_per_s": n_ctx * B * steps / el,
+            "ms_per_tick_per_query": 1e3 * el / steps,
+            "note": "replicas only: independent contexts on their own streams, no exchange"}
+
+
 def cpu_baseline(T, map_size, budget_s=12.0, B=65536, max_ticks=200):
     """The CPU restatement built with the reference's flags, one thread
     (the reference is single-threaded: CMakeLists.txt:7-8), bounded sample."""
@@ -295,6 +329,8 @@ def main():
                 "configs[2] 262144x128 2000x2000": time_config(262144, 128, 2000,
                                                                 max(20, args.steps // 4),
                                                                 max(5, args.warmup // 4)),
+                "configs[4] 8 queries x 16384x64 per GPU": time_multi_query(8, 16384, 64, MAP,
+                                                                            args.steps, args.warmup),
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, MAP)

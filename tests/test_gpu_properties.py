@@ -202,3 +202,47 @@ def test_too_many_path_align_samples_is_refused():
     with pytest.raises(SmpcError) as e:
         g.optimize(scn.tick, scn.u0)
     assert e.value.code == A.SMPC_ERR_UNSUPPORTED
+
+
+def test_multi_query_contexts_are_independent():
+    """BASELINE configs[4] (multi-query: replicas only): contexts ticking concurrently from their
+    own host threads and streams give exactly what each gives alone."""
+    import threading
+    from mpcholonavigation_amd.optimizer import Smpc
+    from tests.helpers import configure, make_case
+    cases = [make_case(4096, 64, seed=40 + i, noise_seed=100 + i) for i in range(4)]
+    alone = []
+    for cfg, scn, noise in cases:
+        g = Smpc(cfg)
+        configure(g, scn, noise=noise)
+        u = scn.u0
+        for _ in range(3):
+            u, out = g.optimize(scn.tick, u)
+        alone.append((u.copy(), out.furthest_reached_path_point, out.non_colliding))
+        g.close()
+    ctxs = []
+    for cfg, scn, noise in cases:
+        g = Smpc(cfg)
+        configure(g, scn, noise=noise)
+        ctxs.append(g)
+    res = [None] * len(cases)
+    go = threading.Barrier(len(cases))
+
+    def run(i):
+        g, (cfg, scn, noise) = ctxs[i], cases[i]
+        u = scn.u0
+        go.wait()
+        for _ in range(3):
+            u, out = g.optimize(scn.tick, u)
+        res[i] = (u.copy(), out.furthest_reached_path_point, out.non_colliding)
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(len(cases))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for (ua, fa, na), (uc, fc, nc) in zip(alone, res):
+        assert fa == fc and na == nc
+        assert np.array_equal(ua, uc)
+    for g in ctxs:
+        g.close()
