@@ -400,3 +400,23 @@ def test_other_registered_critics_parity(Smpc, Oracle, names, power, near, B, T)
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
                   label=f"critics {names} power {power} near {near}")
     assert og.pass_kind == 0       # the general wave-per-rollout pass scores these
+
+
+@pytest.mark.parametrize("lane", [False, True])
+def test_huge_yaw_takes_the_checked_sincos(Smpc, Oracle, lane):
+    """A rollout whose yaw leaves the range of the fast sin/cos reduction (|yaw| >= 65536):
+    the wave pass branches to the library sin/cos for that lane, the lane pass notices it at
+    the end of the group and redoes the group with the checked instance.  Supplied noise with
+    a few absurd wz samples; everything else as usual."""
+    cfg, scn, noise = make_case(4096, 64)
+    if lane:
+        cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+    nvx, nvy, nwz = [n.copy() for n in noise]
+    nwz[5, 3] = 3.0e7          # yaw jumps to 1.5e6 rad at step 4 and stays there
+    nwz[70, 10] = -2.5e8
+    nwz[4000, 62] = 9.0e6      # only the last steps
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, (nvx, nvy, nwz))
+    assert og.pass_kind == (1 if lane else 0)
+    assert og.non_colliding == oo.non_colliding
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
+                  label=f"huge yaw lane={lane}")
