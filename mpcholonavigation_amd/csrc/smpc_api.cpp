@@ -718,6 +718,11 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     Lt.scr_stride = align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);   // parked wz + weights
     Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
     c->lds_tpr = Lt;
+    if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
+  }
+  if (c->lane_now) {
+    const uint32_t lblock = smpc_lane_block();
+    const SmpcLds& Lt = c->lds_tpr;
     if (c->occ_tpr_lds != Lt.total) {
       int nb = 0;
       if (smpc_lane_occupancy(T == 64, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;

@@ -17,3 +17,14 @@ def oracle_lib():
     from oracle import loader
     loader.build()
     return loader.load()
+
+
+@pytest.fixture(params=["default", "lane"])
+def both_passes(request, monkeypatch):
+    """Run a GPU test twice: with the library's own choice of streaming pass and with the
+    lane-per-rollout pass forced wherever it applies (SMPC_PASS is read at smpc_create)."""
+    if request.param == "lane":
+        monkeypatch.setenv("SMPC_PASS", "lane")
+    else:
+        monkeypatch.delenv("SMPC_PASS", raising=False)
+    return request.param

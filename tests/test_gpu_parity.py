@@ -57,7 +57,7 @@ def test_rollout_trajectories_match(Smpc, Oracle):
 
 @pytest.mark.parametrize("B,T", [(1000, 30), (2000, 56), (4096, 64), (512, 100), (300, 128),
                                  (256, 200), (1, 64), (7, 2), (65, 1)])
-def test_cruise_parity(Smpc, Oracle, B, T):
+def test_cruise_parity(Smpc, Oracle, B, T, both_passes):
     """All five critics live (cruise scenario), several batch/horizon shapes incl.
     cfg1 (1000x30), the reference default horizon 56, ragged T and tiny batches."""
     cfg, scn, noise = make_case(B, T)
@@ -88,7 +88,7 @@ def test_cfg3_shape_parity(Smpc, Oracle):
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label="cfg3 shape")
 
 
-def test_near_goal_parity(Smpc, Oracle):
+def test_near_goal_parity(Smpc, Oracle, both_passes):
     """Goal 0.4 m ahead: GoalAngle live, PathAlign/PathFollow/PreferForward gated off."""
     cfg, scn, noise = make_case(1000, 30, near_goal=True)
     g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
@@ -96,7 +96,7 @@ def test_near_goal_parity(Smpc, Oracle):
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="near goal")
 
 
-def test_all_collide_sets_fail_flag(Smpc, Oracle):
+def test_all_collide_sets_fail_flag(Smpc, Oracle, both_passes):
     """Every rollout collides -> fail_flag, later critics not scored (critic_manager.cpp:70-73)."""
     cfg, scn, noise = make_case(512, 30, all_lethal=True)
     g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
@@ -114,7 +114,7 @@ def test_all_collide_sets_fail_flag(Smpc, Oracle):
     assert_parity(ug2, og2, uo2, oo2, g.get_costs(), o.get_costs(), label="sticky fail")
 
 
-def test_two_iterations_accumulate_costs(Smpc, Oracle):
+def test_two_iterations_accumulate_costs(Smpc, Oracle, both_passes):
     """iteration_count=2: costs accumulate, furthest point cached."""
     cfg, scn, noise = make_case(2000, 56)
     cfg.iteration_count = 2
@@ -123,7 +123,7 @@ def test_two_iterations_accumulate_costs(Smpc, Oracle):
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="2 iterations")
 
 
-def test_track_unknown_and_off_map(Smpc, Oracle):
+def test_track_unknown_and_off_map(Smpc, Oracle, both_passes):
     """255 cells + rollouts leaving the map: NO_INFORMATION collides unless tracking unknown."""
     for track in (False, True):
         cfg, scn, noise = make_case(1000, 64, map_size=60)   # 3 m map: rollouts leave it
@@ -134,7 +134,7 @@ def test_track_unknown_and_off_map(Smpc, Oracle):
                       label=f"unknown track={track}")
 
 
-def test_blocked_path_gates(Smpc, Oracle):
+def test_blocked_path_gates(Smpc, Oracle, both_passes):
     """Invalid path points: PathFollow skips ahead, PathAlign's occupancy gate stands down."""
     cfg, scn, noise = make_case(1000, 56)
     P = len(scn.tick.path_x)
@@ -154,7 +154,7 @@ def test_blocked_path_gates(Smpc, Oracle):
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label="few invalid")
 
 
-def test_non_default_critic_params(Smpc, Oracle):
+def test_non_default_critic_params(Smpc, Oracle, both_passes):
     """cost_power 2, use_path_orientations, other weights/steps; curved plan; moving robot."""
     cfg, scn, noise = make_case(1500, 60)
     cr = default_critics()
@@ -184,7 +184,7 @@ def test_non_default_critic_params(Smpc, Oracle):
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1, label="custom critics")
 
 
-def test_single_critics(Smpc, Oracle):
+def test_single_critics(Smpc, Oracle, both_passes):
     """Each critic alone (the others disabled) and none at all."""
     names = ["obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward", None]
     for only in names:
@@ -211,7 +211,7 @@ def test_constraints_clip(Smpc, Oracle):
     assert_parity(ug, og, uo, oo, label="clip")
 
 
-def test_closed_loop_ticks(Smpc, Oracle):
+def test_closed_loop_ticks(Smpc, Oracle, both_passes):
     """Ten ticks with the sequence fed back (shifted) like evalControl does."""
     cfg, scn, noise = make_case(2000, 56)
     g, o = Smpc(cfg), Oracle(cfg)
@@ -273,7 +273,7 @@ def test_error_paths(Smpc):
         g.get_generated_trajectories()
 
 
-def test_speculation_miss_is_rescored(Smpc, Oracle):
+def test_speculation_miss_is_rescored(Smpc, Oracle, both_passes):
     """The furthest point of the previous tick is only a guess: when the plan changes
     the pass reports the true value and the tick is re-scored (passes == 2), so the
     result still equals the oracle's.  SMPC_FLAG_NO_SPECULATION gives the two-pass mode."""
@@ -416,7 +416,9 @@ def test_huge_yaw_takes_the_checked_sincos(Smpc, Oracle, lane):
     nwz[70, 10] = -2.5e8
     nwz[4000, 62] = 9.0e6      # only the last steps
     g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, (nvx, nvy, nwz))
-    assert og.pass_kind == (1 if lane else 0)
+    import os
+    if not os.environ.get("SMPC_PASS"):
+        assert og.pass_kind == (1 if lane else 0)
     assert og.non_colliding == oo.non_colliding
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
                   label=f"huge yaw lane={lane}")

@@ -131,7 +131,7 @@ def test_fallback_counter_is_per_object():
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 64, 65, 300, 1024])
-def test_path_length_edges(P):
+def test_path_length_edges(P, both_passes):
     """Plans from a single point to SMPC_MAX_PATH points (argmin over > 64 points, LDS staging)."""
     from mpcholonavigation_amd.optimizer import Smpc
     from oracle.loader import Oracle
@@ -170,7 +170,7 @@ def test_path_too_long_is_refused():
 
 
 @pytest.mark.parametrize("T,step", [(64, 1), (64, 2), (64, 7), (128, 4), (256, 4), (200, 4), (30, 29)])
-def test_path_align_sampling_geometries(T, step):
+def test_path_align_sampling_geometries(T, step, both_passes):
     """trajectory_point_step / horizon combinations: 1..63 samples per rollout, i.e. every
     segment width (16/32/64 lanes) and group size of the flush."""
     from mpcholonavigation_amd.optimizer import Smpc
