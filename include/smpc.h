@@ -109,7 +109,8 @@ typedef struct smpc_config {
  */
 typedef struct smpc_obstacles_params {
   int32_t enabled;
-  int32_t consider_footprint; /* must be 0: point ("circular") mode only      */
+  int32_t consider_footprint; /* 1: SE2 footprint check near obstacles (needs
+                                 smpc_set_footprint; general pass only)         */
   uint32_t cost_power;
   float repulsion_weight;
   float critical_weight;
@@ -160,7 +161,8 @@ typedef struct smpc_prefer_forward_params {
  */
 typedef struct smpc_cost_params {
   int32_t enabled;
-  int32_t consider_footprint; /* must be 0: point ("circular") mode only         */
+  int32_t consider_footprint; /* 1: SE2 footprint check near obstacles (needs
+                                 smpc_set_footprint; general pass only)            */
   uint32_t cost_power;
   float cost_weight;          /* as in the YAML (3.81); divided by 254 inside    */
   float critical_cost;
@@ -325,6 +327,16 @@ int smpc_set_costmap(smpc_ctx* ctx, const uint8_t* cells, uint32_t width,
 /* Supplied-noise (parity) mode: the three [B,T] row-major noise tensors
  * NoiseGenerator holds [ref tools/noise_generator.hpp:97-99], already scaled
  * by the sampling std.  Host pointers; copied. */
+/* The robot footprint for consider_footprint = true (ObstaclesCritic, CostCritic): n_points
+ * (x, y) pairs in the robot frame (costmap_ros->getRobotFootprint()), the layered costmap's
+ * circumscribed radius, and the inflation layer's own cost_scaling_factor (< 0: the costmap
+ * has no inflation layer) — what {Obstacles,Cost}Critic::findCircumscribedCost and
+ * FootprintCollisionChecker::footprintCostAtPose consume [ref obstacles_critic.cpp:52-97,
+ * 203-224, cost_critic.cpp:62-106,175-201].  At most SMPC_MAX_FOOTPRINT points. */
+#define SMPC_MAX_FOOTPRINT 16
+int smpc_set_footprint(smpc_ctx* ctx, const double* xy, uint32_t n_points,
+                       double circumscribed_radius, double layer_cost_scaling_factor);
+
 int smpc_set_noise(smpc_ctx* ctx, const float* noise_vx, const float* noise_vy,
                    const float* noise_wz);
 

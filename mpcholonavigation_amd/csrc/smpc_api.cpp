@@ -151,6 +151,11 @@ struct smpc_ctx {
   bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
   uint32_t last_pass_kind = 0;
+  // consider_footprint: robot footprint (smpc_set_footprint) and the LUT pair built for it
+  std::vector<double> fp_x, fp_y;
+  double fp_circumscribed_radius = 0.0, fp_layer_scale = -1.0;
+  SmpcLut* d_lut_fp = nullptr;   // [2][256]
+  SmpcLut* h_lut_fp = nullptr;   // pinned
   // native RCCL exchange of the batch-sharded tick (smpc_shard_tick)
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 0;
@@ -239,6 +244,8 @@ void free_ctx(smpc_ctx* c)
   if (c->d_map) (void)hipFree(c->d_map);
   if (c->d_tick) (void)hipFree(c->d_tick);
   if (c->d_lut) (void)hipFree(c->d_lut);
+  if (c->d_lut_fp) (void)hipFree(c->d_lut_fp);
+  if (c->h_lut_fp) (void)hipHostFree(c->h_lut_fp);
   if (c->h_lut) (void)hipHostFree(c->h_lut);
   if (c->h_tick) (void)hipHostFree(c->h_tick);
   if (c->h_out) (void)hipHostFree(c->h_out);
@@ -305,18 +312,21 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
 }
 
 // distanceToObstacle (obstacles_critic.cpp:99-112) for an 8-bit cost, point mode
-float distance_to_obstacle(const HostCostmap& m, float cost)
+float distance_to_obstacle(const HostCostmap& m, float cost, bool using_footprint = false)
 {
   const float scale_factor = m.cost_scaling_factor;
   const float min_radius = m.inscribed_radius;
   float d = static_cast<float>(
     (static_cast<double>(scale_factor * min_radius) - std::log(static_cast<double>(cost)) +
     std::log(static_cast<double>(253.0f))) / static_cast<double>(scale_factor));
-  d -= min_radius;
+  if (!using_footprint) d -= min_radius;   // obstacles_critic.cpp:106-108
   return d;
 }
 
-void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut)
+// consider_fp: the critic's consider_footprint collision rule; using_fp: the cost came from the
+// footprint (no inscribed-radius offset, obstacles_critic.cpp:106-108)
+void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut, bool consider_fp = false,
+               bool using_fp = false)
 {
   const auto& m = c->map;
   const auto& p = c->critics.obstacles;
@@ -324,7 +334,7 @@ void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut)
     lut[v].crit = 0.f;
     lut[v].rep = 0.f;
     // inCollision (obstacles_critic.cpp:185-201), consider_footprint = false
-    if (v == SMPC_COST_LETHAL || v == SMPC_COST_INSCRIBED ||
+    if (v == SMPC_COST_LETHAL || (v == SMPC_COST_INSCRIBED && !consider_fp) ||
       (v == SMPC_COST_NO_INFORMATION && !m.track_unknown))
     {
       lut[v].crit = -1.0f;                                   // :152 collision marker
@@ -332,7 +342,7 @@ void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut)
     }
     if (v < 1) continue;                                     // :150 free space
     if (m.inflation_radius == 0.0f || m.cost_scaling_factor == 0.0f) continue;  // :155
-    const float d = distance_to_obstacle(m, static_cast<float>(v));
+    const float d = distance_to_obstacle(m, static_cast<float>(v), using_fp);
     if (d < p.collision_margin_distance) {
       lut[v].crit = p.collision_margin_distance - d;         // :165
     } else if (!near_goal) {
@@ -351,8 +361,15 @@ int check_tick(smpc_ctx* c, const smpc_tick_in* in)
     return fail(c, SMPC_ERR_UNSUPPORTED, "path longer than SMPC_MAX_PATH (1024) points");
   if (!c->map.set && (c->critics.obstacles.enabled || c->critics.cost.enabled || !in->path_pts_valid))
     return fail(c, SMPC_ERR_STATE, "no costmap: call smpc_set_costmap");
-  if (c->critics.obstacles.consider_footprint || (c->critics.cost.enabled && c->critics.cost.consider_footprint))
-    return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
+  if (((c->critics.obstacles.enabled && c->critics.obstacles.consider_footprint) ||
+    (c->critics.cost.enabled && c->critics.cost.consider_footprint)) && c->fp_x.empty())
+    return fail(c, SMPC_ERR_STATE, "consider_footprint=true needs a footprint: call smpc_set_footprint");
+  // with a footprint the two collision critics no longer see the same set of colliding
+  // rollouts, and the tuple carries one non-colliding count
+  if (c->critics.obstacles.enabled && c->critics.cost.enabled &&
+    (c->critics.obstacles.consider_footprint || c->critics.cost.consider_footprint))
+    return fail(c, SMPC_ERR_UNSUPPORTED,
+                "consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
   return SMPC_OK;
 }
 
@@ -402,6 +419,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // the other registered critics (general pass only)
   if (cr.constraint.enabled) gates |= SD_CONSTRAINT;
   if (cr.cost.enabled) gates |= SD_COST;
+  if (cr.obstacles.enabled && cr.obstacles.consider_footprint) gates |= SD_FP_OBSTACLES;
+  if (cr.cost.enabled && cr.cost.consider_footprint) gates |= SD_FP_COST;
   if (cr.goal.enabled && within_tol(cr.goal.threshold_to_consider, rx, ry, gx, gy))
     gates |= SD_GOAL;                                         // goal_critic.cpp:38-42
   if (cr.twirling.enabled) {
@@ -584,11 +603,18 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // ---- Obstacles LUT: rebuilt and uploaded only when its inputs changed -----------
   if (gates & (SD_OBSTACLES | SD_COST)) {
     const bool near_goal = within_tol(cr.obstacles.near_goal_distance, rx, ry, gx, gy);  // :124-127
-    const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 1) ^ (near_goal ? 1u : 0u);
+    const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 2) ^ (near_goal ? 1u : 0u) ^
+      ((gates & (SD_FP_OBSTACLES | SD_FP_COST)) ? 2u : 0u);
     if (!c->lut_valid || key != c->lut_key) {
       build_lut(c, near_goal, c->h_lut);
       HIPCK(c, hipMemcpyAsync(c->d_lut, c->h_lut, 256 * sizeof(SmpcLut), hipMemcpyHostToDevice,
                               c->stream));
+      if (gates & (SD_FP_OBSTACLES | SD_FP_COST)) {
+        build_lut(c, near_goal, c->h_lut_fp, true, false);
+        build_lut(c, near_goal, c->h_lut_fp + 256, true, true);
+        HIPCK(c, hipMemcpyAsync(c->d_lut_fp, c->h_lut_fp, 512 * sizeof(SmpcLut), hipMemcpyHostToDevice,
+                                c->stream));
+      }
       c->lut_key = key;
       c->lut_valid = true;
     }
@@ -662,6 +688,33 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.db_vy = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[1]));
   d.db_wz = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[2]));
   d.db_weight = cr.velocity_deadband.cost_weight; d.db_power = cr.velocity_deadband.cost_power;
+  d.lut_fp = c->d_lut_fp;
+  d.fp_n = static_cast<uint32_t>(c->fp_x.size());
+  for (uint32_t i = 0; i < d.fp_n; ++i) {
+    d.fp_x[i] = c->fp_x[i];
+    d.fp_y[i] = c->fp_y[i];
+  }
+  d.fp_pic = 0.0f;
+  if (gates & (SD_FP_OBSTACLES | SD_FP_COST)) {
+    // {Obstacles,Cost}Critic::findCircumscribedCost with InflationLayer::computeCost
+    // (nav2_costmap_2d, Humble): the cost at the circumscribed radius, -1 without a layer
+    double result = -1.0;
+    if (c->fp_layer_scale >= 0.0) {
+      const double distance = c->fp_circumscribed_radius / c->map.res;
+      unsigned char cost = 0;
+      if (distance == 0) {
+        cost = SMPC_COST_LETHAL;
+      } else if (distance * c->map.res <= static_cast<double>(c->map.inscribed_radius)) {
+        cost = SMPC_COST_INSCRIBED;
+      } else {
+        const double factor = std::exp(-1.0 * c->fp_layer_scale *
+                                       (distance * c->map.res - static_cast<double>(c->map.inscribed_radius)));
+        cost = static_cast<unsigned char>((SMPC_COST_INSCRIBED - 1) * factor);
+      }
+      result = cost;
+    }
+    d.fp_pic = static_cast<float>(result);
+  }
   d.g_vx = c->cfg.gamma / powf(c->cfg.vx_std, 2);
   d.g_vy = c->cfg.gamma / powf(c->cfg.vy_std, 2);
   d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
@@ -1046,6 +1099,9 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipHostMalloc(&c->h_tick, c->tick_cap, hipHostMallocDefault));
   CK(hipMalloc(&c->d_lut, 256 * sizeof(SmpcLut)));
   CK(hipMemset(c->d_lut, 0, 256 * sizeof(SmpcLut)));
+  CK(hipMalloc(&c->d_lut_fp, 512 * sizeof(SmpcLut)));
+  CK(hipMemset(c->d_lut_fp, 0, 512 * sizeof(SmpcLut)));
+  CK(hipHostMalloc(&c->h_lut_fp, 512 * sizeof(SmpcLut), hipHostMallocDefault));
   CK(hipHostMalloc(&c->h_lut, 256 * sizeof(SmpcLut), hipHostMallocDefault));
   const size_t TL = 4 + 3 * static_cast<size_t>(T);
   CK(hipMalloc(&c->d_partials, kMaxGrid * TL * sizeof(float)));
@@ -1090,12 +1146,26 @@ int smpc_set_constraints(smpc_ctx* c, float vx_max, float vx_min, float vy_max, 
   return SMPC_OK;
 }
 
+int smpc_set_footprint(smpc_ctx* c, const double* xy, uint32_t n_points, double circumscribed_radius,
+                       double layer_cost_scaling_factor)
+{
+  if (!c || (n_points && !xy)) return fail(c, SMPC_ERR_INVALID, "null argument");
+  if (n_points > SMPC_MAX_FOOTPRINT) return fail(c, SMPC_ERR_UNSUPPORTED, "footprint with more than 16 points");
+  c->fp_x.clear();
+  c->fp_y.clear();
+  for (uint32_t i = 0; i < n_points; ++i) {
+    c->fp_x.push_back(xy[2 * i]);
+    c->fp_y.push_back(xy[2 * i + 1]);
+  }
+  c->fp_circumscribed_radius = circumscribed_radius;
+  c->fp_layer_scale = layer_cost_scaling_factor;
+  c->critics_version++;
+  return SMPC_OK;
+}
+
 int smpc_set_critics(smpc_ctx* c, const smpc_critic_params* p)
 {
   if (!c || !p) return SMPC_ERR_INVALID;
-  if ((p->obstacles.enabled && p->obstacles.consider_footprint) ||
-    (p->cost.enabled && p->cost.consider_footprint))
-    return fail(c, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is outside the hot-path scope");
   c->critics = *p;
   c->critics_version++;
   return SMPC_OK;

@@ -23,7 +23,10 @@
 #define SD_TWIRLING 0x4000u
 #define SD_PATH_ANGLE 0x8000u
 #define SD_DEADBAND 0x10000u
-#define SD_EXTRA_CRITICS (SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE | SD_DEADBAND)
+#define SD_FP_OBSTACLES 0x20000u   // ObstaclesCritic consider_footprint
+#define SD_FP_COST 0x40000u        // CostCritic consider_footprint
+#define SD_EXTRA_CRITICS (SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE | SD_DEADBAND | \
+                          SD_FP_OBSTACLES | SD_FP_COST)
 
 #define SMPC_MAX_PATH 1024        // path points staged in LDS
 #define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
@@ -110,6 +113,13 @@ struct SmpcDev {
   double db_vx, db_vy, db_wz;                    // |deadband_velocities|
   float db_weight;
   uint32_t db_power;
+  // consider_footprint: footprint polygon (robot frame), possibly-inscribed cost
+  // (findCircumscribedCost), and the LUT pair for the consider_footprint collision rule:
+  // [0] cost from the centre point, [1] cost from the footprint (no inscribed-radius offset)
+  uint32_t fp_n;
+  float fp_pic;
+  const SmpcLut* lut_fp;                         // [2][256]
+  double fp_x[16], fp_y[16];
   float g_vx, g_vy, g_wz;  // gamma / std^2 (optimizer.cpp:367-379)
   float neg_inv_temp;      // -1 / temperature (optimizer.cpp:383)
   float k2;                // neg_inv_temp * log2(e): weights as 2^(k2 (c - min))

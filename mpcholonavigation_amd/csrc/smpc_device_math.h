@@ -129,4 +129,80 @@ __device__ __forceinline__ uint32_t cost_at(const SmpcDev& p, const CellConsts& 
 }
 
 
+// ---- consider_footprint = true (general pass only): nav2_costmap_2d's
+// FootprintCollisionChecker::footprintCostAtPose with nav2_util::LineIterator, restated
+// (third party, ROS 2 Humble).  Costs come from the LDS window when the cell is inside it.
+__device__ __noinline__ uint32_t cell_cost(const SmpcDev& p, const uint8_t* s_map, uint32_t mx,
+                                           uint32_t my)
+{
+  const uint32_t lx = mx - (uint32_t)p.win_x0, ly = my - (uint32_t)p.win_y0;
+  const bool inw = lx < (uint32_t)p.win_w && ly < (uint32_t)p.win_h;
+  uint32_t c = s_map[inw ? ly * p.win_w + lx : 0u];
+  if (!inw) c = p.map[(size_t)my * p.W + mx];
+  return c;
+}
+
+__device__ __noinline__ float footprint_line_cost(const SmpcDev& p, const uint8_t* s_map, int x0,
+                                                  int x1, int y0, int y1)
+{
+  float cost = 0.f;
+  const int deltax = abs(x1 - x0), deltay = abs(y1 - y0);
+  int x = x0, y = y0;
+  int xinc1 = x1 >= x0 ? 1 : -1, xinc2 = xinc1;
+  int yinc1 = y1 >= y0 ? 1 : -1, yinc2 = yinc1;
+  int den, num, numadd, numpixels;
+  if (deltax >= deltay) {
+    xinc1 = 0; yinc2 = 0; den = deltax; num = deltax / 2; numadd = deltay; numpixels = deltax;
+  } else {
+    xinc2 = 0; yinc1 = 0; den = deltay; num = deltay / 2; numadd = deltax; numpixels = deltay;
+  }
+  for (int curpixel = 0; curpixel <= numpixels; ++curpixel) {
+    const float pc = (float)cell_cost(p, s_map, (uint32_t)x, (uint32_t)y);
+    if (pc == 254.0f) return pc;          // LETHAL_OBSTACLE
+    cost = fmaxf(cost, pc);
+    num += numadd;
+    if (num >= den) {
+      num -= den;
+      x += xinc1;
+      y += yinc1;
+    }
+    x += xinc2;
+    y += yinc2;
+  }
+  return cost;
+}
+
+__device__ __noinline__ float footprint_cost_at_pose(const SmpcDev& p, const uint8_t* s_map, float xf,
+                                                     float yf, float thetaf)
+{
+  const double x = (double)xf, y = (double)yf, theta = (double)thetaf;
+  const double cos_th = cos(theta), sin_th = sin(theta);
+  const uint32_t n = p.fp_n;
+  uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0, xs = 0, ys = 0;
+  float fc = 0.f;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double wx = x + (p.fp_x[i] * cos_th - p.fp_y[i] * sin_th);
+    const double wy = y + (p.fp_x[i] * sin_th + p.fp_y[i] * cos_th);
+    uint32_t mx = 0, my = 0;
+    bool on = cell_index_exact(wx, p.ox, p.res, p.W, mx);
+    on = cell_index_exact(wy, p.oy, p.res, p.H, my) && on;
+    if (!on) return 254.0f;               // a vertex off the map
+    if (i == 0) {
+      xs = x0 = mx;
+      ys = y0 = my;
+      x1 = mx;
+      y1 = my;
+      continue;
+    }
+    x1 = mx;
+    y1 = my;
+    fc = fmaxf(footprint_line_cost(p, s_map, (int)x0, (int)x1, (int)y0, (int)y1), fc);
+    x0 = x1;
+    y0 = y1;
+    if (fc == 254.0f) return fc;
+  }
+  if (n == 0) return 254.0f;
+  return fmaxf(footprint_line_cost(p, s_map, (int)xs, (int)x1, (int)ys, (int)y1), fc);
+}
+
 #endif

@@ -676,6 +676,82 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       cost = add_cost_pow(cost, wave_sum_d(sa) * (double)p.con_weight, p.con_power);
     }
 
+    // ---- consider_footprint = true for either collision critic: MODE 2 only ----------
+    // (obstacles_critic.cpp:139-171,203-224; cost_critic.cpp:128-166,175-201.)  The centre
+    // cost is looked up as always; a step whose centre cost reaches the possibly-inscribed
+    // cost gets the SE2 footprint cost.  Obstacles scores the footprint cost, Cost scores the
+    // centre cost and only collision-checks with the footprint; each critic keeps its own
+    // first collision.
+    if (RARE && (p.flags & (SD_FP_OBSTACLES | SD_FP_COST))) {
+      float crit = 0.f, rep = 0.f, crep = 0.f;
+      int first_o = R, first_c = R;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!STEP_OK(r)) continue;
+        const uint32_t c = (t0 + r == 0) ? p.cost_t0 : cost_at(p, cellk, s_map, x[r], y[r]);
+        // off the map: NO_INFORMATION without a footprint check (costAtPose returns early)
+        uint32_t mxe = 0, mye = 0;
+        bool on = cell_index_exact((double)x[r], p.ox, p.res, p.W, mxe);
+        on = cell_index_exact((double)y[r], p.oy, p.res, p.H, mye) && on;
+        // Obstacles checks the footprint inside costAtPose (on-map centres only); Cost checks it
+        // inside inCollision, also for an off-map centre (cost NO_INFORMATION)
+        const bool cond = (float)c >= p.fp_pic || p.fp_pic < 1.0f;
+        const bool want_o = (p.flags & SD_OBSTACLES) && (p.flags & SD_FP_OBSTACLES) && first_o == R &&
+                            cond && on;
+        const bool want_c = (p.flags & SD_COST) && (p.flags & SD_FP_COST) && first_c == R && cond &&
+                            c >= 1u;
+        float cf = (float)c;
+        if (want_o || want_c) cf = footprint_cost_at_pose(p, s_map, x[r], y[r], yaw[r]);
+        if ((p.flags & SD_OBSTACLES) && first_o == R) {
+          const bool fpo = (p.flags & SD_FP_OBSTACLES) != 0;
+          const uint32_t co = want_o ? (uint32_t)cf : c;
+          const SmpcLut e = fpo ? p.lut_fp[(want_o ? 256u : 0u) + co] : s_lut[co];
+          if (e.crit < 0.f) {
+            first_o = r;
+          } else {
+            crit += e.crit;
+            rep += e.rep;
+          }
+        }
+        if ((p.flags & SD_COST) && first_c == R && c >= 1u) {
+          const bool fpc = (p.flags & SD_FP_COST) != 0;
+          const uint32_t cc = want_c ? (uint32_t)cf : c;
+          const float marker = fpc ? p.lut_fp[cc].crit : s_lut[cc].crit;
+          if (marker < 0.f) first_c = r;
+          else crep += p.lut_cost[c];
+        }
+      }
+      bool coll_o = false, coll_c = false;
+      if (p.flags & SD_OBSTACLES) {
+        const unsigned long long cm = __ballot(first_o < R);
+        coll_o = cm != 0ull;
+        if (coll_o) {
+          const int lc = __ffsll((long long)cm) - 1;
+          if (lane > lc) rep = 0.f;
+        }
+      }
+      if (p.flags & SD_COST) {
+        const unsigned long long cm = __ballot(first_c < R);
+        coll_c = cm != 0ull;
+        if (coll_c) {
+          const int lc = __ffsll((long long)cm) - 1;
+          if (lane > lc) crep = 0.f;
+        }
+      }
+      // the critic that would stop the manager decides the batch-wide fail flag: Cost first
+      if (!((p.flags & SD_COST) ? coll_c : coll_o)) n_noncoll++;
+      if (p.flags & SD_COST) {
+        const float repulsive = coll_c ? p.cost_collision_cost : wave_sum(crep);
+        const float v = p.cost_w254 * repulsive / (float)T;
+        cost = add_cost_pow(cost, (double)v, p.cost_power);
+      }
+      if (p.flags & SD_OBSTACLES) {
+        const float rep_sum = wave_sum(rep);
+        const float raw = coll_o ? p.obs_collision_cost : wave_sum(crit);
+        const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
+        cost = add_cost_pow(cost, (double)v, p.obs_power);
+      }
+    } else
     // ---- costmap lookups shared by CostCritic and ObstaclesCritic ----------------
     // (cost_critic.cpp:128-166, obstacles_critic.cpp:114-178: the same costAtPose and the same
     // inCollision switch in point mode, so one lookup and one first-collision search)
@@ -936,12 +1012,30 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
   __shared__ float s_acc[32][33];
   const uint32_t TL = 4 + 3 * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-  float m = 3.0e38f, fu = 0.f, nc = 0.f;
-  for (uint32_t g = tid; g < nblk; g += blockDim.x) {
-    m = fminf(m, partials[(size_t)g * TL]);
-    fu = fmaxf(fu, partials[(size_t)g * TL + 2]);
-    nc += partials[(size_t)g * TL + 3];
+  const uint32_t col = blockIdx.x * 32 + (tid & 31);
+  const uint32_t sl = tid >> 5;  // 32 slices
+  const bool colon = col < TL && col != 0 && col != 2 && col != 3;
+  // Every global load this thread needs is issued before the first wait: the tuple headers
+  // {min, sum w, furthest, non-colliding} of (up to two) partials, and the first 16 rows of
+  // its column — one memory round trip instead of five dependent ones.
+  float hm[2], hw[2], hf[2], hn[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t g = tid + k * 1024;
+    const bool on = g < nblk;
+    const float* h = partials + (size_t)(on ? g : 0) * TL;
+    hm[k] = on ? h[0] : 3.0e38f;
+    hw[k] = on ? h[1] : 0.f;
+    hf[k] = on ? h[2] : 0.f;
+    hn[k] = on ? h[3] : 0.f;
   }
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t g = sl + 32 * k;
+    v[k] = (colon && g < nblk) ? partials[(size_t)g * TL + col] : 0.f;
+  }
+  float m = fminf(hm[0], hm[1]), fu = fmaxf(hf[0], hf[1]), nc = hn[0] + hn[1];
   for (int o = 32; o > 0; o >>= 1) {
     m = fminf(m, __shfl_xor(m, o, WAVE));
     fu = fmaxf(fu, __shfl_xor(fu, o, WAVE));
@@ -961,49 +1055,52 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
     fu = fmaxf(fu, s_red2[w]);
     nc += s_red3[w];
   }
-  // per-block rescale factors exp(-(m_g - m)/temperature), once
-  for (uint32_t g = tid; g < nblk; g += blockDim.x)
-    s_sc[g] = expf(neg_inv_temp * (partials[(size_t)g * TL] - m));
-  __syncthreads();
-  const uint32_t col = blockIdx.x * 32 + (tid & 31);
-  const uint32_t sl = tid >> 5;  // 32 slices
+  // per-block rescale factors exp(-(m_g - m)/temperature), once; sum of weights from the headers
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t g = tid + k * 1024;
+    if (g < nblk) {
+      const float sc = expf(neg_inv_temp * (hm[k] - m));
+      s_sc[g] = sc;
+      a += sc * hw[k];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+  __syncthreads();   // s_sc complete, s_red* free again
+  if (lane == 0) s_red[wave] = a;
   float acc = 0.f;
-  if (col < TL && col != 0 && col != 2 && col != 3) {
-#pragma unroll 4
-    for (uint32_t g = sl; g < nblk; g += 32) acc += s_sc[g] * partials[(size_t)g * TL + col];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t g = sl + 32 * k;
+    if (g < nblk) acc += s_sc[g] * v[k];
+  }
+  if (colon) {   // grids beyond 512 blocks: the rest of the column
+    for (uint32_t g = sl + 512; g < nblk; g += 32) acc += s_sc[g] * partials[(size_t)g * TL + col];
   }
   s_acc[sl][tid & 31] = acc;
-  // sum of weights (tuple column 1), needed by every block when it finishes its columns
-  float sw = 0.f;
-  if (fin.enabled) {
-    float a = 0.f;
-    for (uint32_t g = tid; g < nblk; g += blockDim.x) a += s_sc[g] * partials[(size_t)g * TL + 1];
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
-    __syncthreads();   // s_red* free again
-    if (lane == 0) s_red[wave] = a;
-  }
   __syncthreads();
-  if (fin.enabled) {
-    for (int w = 0; w < nwave; ++w) sw += s_red[w];
-  }
+  float sw = 0.f;
+  for (int w = 0; w < nwave; ++w) sw += s_red[w];
   if (sl == 0 && col < TL) {
     float r = 0.f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) r += s_acc[s][tid & 31];
     if (col == 0) r = m;
+    if (col == 1) r = sw;
     if (col == 2) r = fu;
     if (col == 3) r = nc;
     tuple[col] = r;
     if (fin.enabled) {
       if (col >= 4) {
         const uint32_t i = col - 4;
-        float v = r / sw;
+        float v2 = r / sw;
         // applyControlSequenceConstraints (optimizer.cpp:237-249)
-        if (i < T) v = fminf(fmaxf(v, fin.vx_min), fin.vx_max);
-        else if (i < 2 * T) v = fminf(fmaxf(v, -fin.vy_max), fin.vy_max);
-        else v = fminf(fmaxf(v, -fin.wz_max), fin.wz_max);
-        fin.u_dev[i] = v;
-        fin.u_host[i] = v;
+        if (i < T) v2 = fminf(fmaxf(v2, fin.vx_min), fin.vx_max);
+        else if (i < 2 * T) v2 = fminf(fmaxf(v2, -fin.vy_max), fin.vy_max);
+        else v2 = fminf(fmaxf(v2, -fin.wz_max), fin.wz_max);
+        fin.u_dev[i] = v2;
+        fin.u_host[i] = v2;
       } else if (col == 0) {
         const float used = fin.furthest_used ? *fin.furthest_used : fu;
         const float res[5] = {m, sw, fu, nc, used};

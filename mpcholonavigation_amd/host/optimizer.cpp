@@ -165,6 +165,12 @@ void Optimizer::setCostmap(const CostmapView & m)
       ctx_, m.cells, m.size_x, m.size_y, m.origin_x, m.origin_y, m.resolution,
       m.track_unknown ? 1 : 0, m.inscribed_radius, infl ? critics_.cost_scaling_factor : 0.0f,
       infl ? critics_.inflation_radius : 0.0f), "smpc_set_costmap");
+  if (!m.footprint_xy.empty()) {
+    ck(
+      ctx_, smpc_set_footprint(
+        ctx_, m.footprint_xy.data(), static_cast<uint32_t>(m.footprint_xy.size() / 2),
+        m.circumscribed_radius, infl ? m.layer_cost_scaling_factor : -1.0), "smpc_set_footprint");
+  }
 }
 
 void Optimizer::setNoise(const float * nvx, const float * nvy, const float * nwz)

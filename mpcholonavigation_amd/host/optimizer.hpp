@@ -99,6 +99,11 @@ struct CostmapView
   bool track_unknown{false};
   float inscribed_radius{0};
   bool has_inflation_layer{false};
+  // consider_footprint = true: costmap_ros->getRobotFootprint() as (x, y) pairs, the layered
+  // costmap's circumscribed radius, the inflation layer's own cost_scaling_factor
+  std::vector<double> footprint_xy;
+  double circumscribed_radius{0};
+  double layer_cost_scaling_factor{-1.0};
 };
 
 struct CriticsConfig

@@ -104,6 +104,12 @@ class Smpc:
             self.h, _ptr(cells), w, h, origin_x, origin_y, resolution, int(track_unknown),
             inscribed_radius, cost_scaling_factor, inflation_radius))
 
+    def set_footprint(self, xy, circumscribed_radius, layer_cost_scaling_factor=10.0):
+        """Robot footprint [n, 2] (robot frame) for consider_footprint=true."""
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._ck(self.lib.smpc_set_footprint(self.h, xy.ctypes.data_as(C.c_void_p), len(xy),
+                                             float(circumscribed_radius), float(layer_cost_scaling_factor)))
+
     def set_noise(self, nvx, nvy, nwz):
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (nvx, nvy, nwz)]
         for x in a:

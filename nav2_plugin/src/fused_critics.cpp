@@ -54,11 +54,7 @@ getParam(p.collision_margin_distance, "collision_margin_distance", 0.10);
 getParam(p.near_goal_distance, "near_goal_distance", 0.5);
 getParam(e.cost_scaling_factor, "cost_scaling_factor", 10.0);
 getParam(e.inflation_radius, "inflation_radius", 0.55);
-p.consider_footprint = consider_footprint;
-if (consider_footprint) {
-  throw std::runtime_error(
-          "ObstaclesCritic: consider_footprint=true is not on the MI355X path yet");
-}
+p.consider_footprint = consider_footprint;   // footprint uploaded with the costmap
 FUSED_CRITIC_END
 
 FUSED_CRITIC_BEGIN(PathAlignCritic)   // ref src/critics/path_align_critic.cpp:26-38
@@ -110,11 +106,7 @@ getParam(p.cost_weight, "cost_weight", 3.81);   // libsmpc divides by 254 like :
 getParam(p.critical_cost, "critical_cost", 300.0);
 getParam(p.collision_cost, "collision_cost", 1000000.0);
 getParam(p.near_goal_distance, "near_goal_distance", 0.5);
-p.consider_footprint = consider_footprint;
-if (consider_footprint) {
-  throw std::runtime_error(
-          "CostCritic: consider_footprint=true is not on the MI355X path yet");
-}
+p.consider_footprint = consider_footprint;   // footprint uploaded with the costmap
 FUSED_CRITIC_END
 
 FUSED_CRITIC_BEGIN(GoalCritic)   // ref src/critics/goal_critic.cpp:26-28

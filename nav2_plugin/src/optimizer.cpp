@@ -90,10 +90,17 @@ void Optimizer::uploadCostmap()
   v.track_unknown = layered->isTrackingUnknown();
   v.inscribed_radius = layered->getInscribedRadius();
   for (auto & layer : *layered->getPlugins()) {   // obstacles_critic.cpp:66-74
-    if (std::dynamic_pointer_cast<nav2_costmap_2d::InflationLayer>(layer)) {
+    if (auto inflation = std::dynamic_pointer_cast<nav2_costmap_2d::InflationLayer>(layer)) {
       v.has_inflation_layer = true;
+      v.layer_cost_scaling_factor = inflation->getCostScalingFactor();
     }
   }
+  // consider_footprint = true (obstacles_critic.cpp:215-221, cost_critic.cpp:181-186)
+  for (const auto & pt : costmap_ros_->getRobotFootprint()) {
+    v.footprint_xy.push_back(pt.x);
+    v.footprint_xy.push_back(pt.y);
+  }
+  v.circumscribed_radius = layered->getCircumscribedRadius();
   host_.setCostmap(v);
 }
 

@@ -26,6 +26,7 @@ _PROTOTYPES = {
     "smpc_oracle_set_costmap": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
                                           C.c_double, C.c_double, C.c_int, C.c_float, C.c_float,
                                           C.c_float]),
+    "smpc_oracle_set_footprint": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_double, C.c_double]),
     "smpc_oracle_set_noise": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     "smpc_oracle_seed": (C.c_int, [_ctx, C.c_uint64]),
     "smpc_oracle_get_noise": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
@@ -157,6 +158,12 @@ class Oracle:
         self._ck(self.lib.smpc_oracle_set_costmap(
             self.h, ptr(cells), w, h, origin_x, origin_y, resolution, int(track_unknown),
             inscribed_radius, cost_scaling_factor, inflation_radius))
+
+    def set_footprint(self, xy, circumscribed_radius, layer_cost_scaling_factor=10.0):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._ck(self.lib.smpc_oracle_set_footprint(self.h, xy.ctypes.data_as(C.c_void_p), len(xy),
+                                                    float(circumscribed_radius),
+                                                    float(layer_cost_scaling_factor)))
 
     def set_noise(self, nvx, nvy, nwz):
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (nvx, nvy, nwz)]

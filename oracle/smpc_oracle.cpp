@@ -107,6 +107,11 @@ struct Costmap {
   float cost_scaling_factor = 0;  // ObstaclesCritic::inflation_scale_factor_
   float inflation_radius = 0;     // ObstaclesCritic::inflation_radius_
   bool set = false;
+  // consider_footprint: robot footprint polygon (robot frame), the layered
+  // costmap's circumscribed radius and the inflation layer's own cost_scaling_factor (< 0: none)
+  std::vector<double> fp_x, fp_y;
+  double circumscribed_radius = 0.0;
+  double layer_cost_scaling_factor = -1.0;
 };
 
 inline bool world_to_map(const Costmap & c, double wx, double wy, unsigned & mx, unsigned & my)
@@ -551,7 +556,123 @@ void set_path_costs_if_not_set(smpc_oracle * o, const Tick & tk)
   }
 }
 
-// ObstaclesCritic (src/critics/obstacles_critic.cpp:99-224), consider_footprint=false
+
+// ---- consider_footprint = true: nav2_costmap_2d (ROS 2 Humble, third party; restated from its
+// published sources: footprint_collision_checker.cpp, nav2_util/line_iterator.hpp,
+// inflation_layer.hpp).  The reference has no test on this path: parity unpinned beyond the
+// GPU-vs-oracle comparison.
+
+// InflationLayer::computeCost(distance in cells)
+inline unsigned char inflation_compute_cost(const Costmap & cm, double distance)
+{
+  unsigned char cost = 0;
+  if (distance == 0) {
+    cost = SMPC_COST_LETHAL;
+  } else if (distance * cm.res <= static_cast<double>(cm.inscribed_radius)) {
+    cost = SMPC_COST_INSCRIBED;
+  } else {
+    const double factor =
+      std::exp(-1.0 * cm.layer_cost_scaling_factor * (distance * cm.res - static_cast<double>(cm.inscribed_radius)));
+    cost = static_cast<unsigned char>((SMPC_COST_INSCRIBED - 1) * factor);
+  }
+  return cost;
+}
+
+// {Obstacles,Cost}Critic::findCircumscribedCost (obstacles_critic.cpp:52-97, cost_critic.cpp:62-106)
+inline float find_circumscribed_cost(const Costmap & cm)
+{
+  double result = -1.0;
+  if (cm.layer_cost_scaling_factor >= 0.0) {
+    result = inflation_compute_cost(cm, cm.circumscribed_radius / cm.res);
+  }
+  return static_cast<float>(result);
+}
+
+// FootprintCollisionChecker::lineCost with nav2_util::LineIterator
+inline double line_cost(const Costmap & cm, int x0, int x1, int y0, int y1)
+{
+  double cost = 0.0;
+  const int deltax = std::abs(x1 - x0), deltay = std::abs(y1 - y0);
+  int x = x0, y = y0;
+  int xinc1 = x1 >= x0 ? 1 : -1, xinc2 = xinc1;
+  int yinc1 = y1 >= y0 ? 1 : -1, yinc2 = yinc1;
+  int den, num, numadd, numpixels;
+  if (deltax >= deltay) {
+    xinc1 = 0;
+    yinc2 = 0;
+    den = deltax;
+    num = deltax / 2;
+    numadd = deltay;
+    numpixels = deltax;
+  } else {
+    xinc2 = 0;
+    yinc1 = 0;
+    den = deltay;
+    num = deltay / 2;
+    numadd = deltax;
+    numpixels = deltay;
+  }
+  for (int curpixel = 0; curpixel <= numpixels; ++curpixel) {
+    const double point_cost = static_cast<double>(
+      get_cost(cm, static_cast<unsigned>(x), static_cast<unsigned>(y)));
+    if (point_cost == static_cast<double>(SMPC_COST_LETHAL)) {
+      return point_cost;
+    }
+    if (cost < point_cost) {
+      cost = point_cost;
+    }
+    num += numadd;
+    if (num >= den) {
+      num -= den;
+      x += xinc1;
+      y += yinc1;
+    }
+    x += xinc2;
+    y += yinc2;
+  }
+  return cost;
+}
+
+// FootprintCollisionChecker::footprintCostAtPose + footprintCost
+inline double footprint_cost_at_pose(const Costmap & cm, double x, double y, double theta)
+{
+  const size_t n = cm.fp_x.size();
+  if (n == 0) {
+    return static_cast<double>(SMPC_COST_LETHAL);
+  }
+  const double cos_th = std::cos(theta), sin_th = std::sin(theta);
+  auto vertex = [&](size_t i, unsigned & mx, unsigned & my) {
+      const double wx = x + (cm.fp_x[i] * cos_th - cm.fp_y[i] * sin_th);
+      const double wy = y + (cm.fp_x[i] * sin_th + cm.fp_y[i] * cos_th);
+      return world_to_map(cm, wx, wy, mx, my);
+    };
+  unsigned x0, y0, x1 = 0, y1 = 0;
+  double footprint_cost = 0.0;
+  if (!vertex(0, x0, y0)) {
+    return static_cast<double>(SMPC_COST_LETHAL);
+  }
+  const unsigned xstart = x0, ystart = y0;
+  x1 = x0;
+  y1 = y0;
+  for (size_t i = 0; i + 1 < n; ++i) {
+    if (!vertex(i + 1, x1, y1)) {
+      return static_cast<double>(SMPC_COST_LETHAL);
+    }
+    footprint_cost = std::max(
+      line_cost(cm, static_cast<int>(x0), static_cast<int>(x1), static_cast<int>(y0),
+      static_cast<int>(y1)), footprint_cost);
+    x0 = x1;
+    y0 = y1;
+    if (footprint_cost == static_cast<double>(SMPC_COST_LETHAL)) {
+      return footprint_cost;
+    }
+  }
+  return std::max(
+    line_cost(cm, static_cast<int>(xstart), static_cast<int>(x1), static_cast<int>(ystart),
+    static_cast<int>(y1)), footprint_cost);
+}
+
+// ObstaclesCritic (src/critics/obstacles_critic.cpp:99-232)
 void score_obstacles(smpc_oracle * o, const Tick & tk)
 {
   const auto & p = o->critics.obstacles;
@@ -563,6 +684,8 @@ void score_obstacles(smpc_oracle * o, const Tick & tk)
   // :124-127
   const bool near_goal = within_position_goal_tolerance(
     p.near_goal_distance, tk.in->pose_x, tk.in->pose_y, tk.in->goal_x, tk.in->goal_y);
+  // :119-122
+  const float possibly_inscribed_cost = p.consider_footprint ? find_circumscribed_cost(cm) : 0.0f;
   std::vector<float> raw_cost(B, 0.0f), repulsive_cost(B, 0.0f);
   const size_t traj_len = T;
   bool all_trajectories_collide = true;
@@ -573,11 +696,19 @@ void score_obstacles(smpc_oracle * o, const Tick & tk)
     for (size_t j = 0; j < traj_len; j++) {
       // costAtPose :203-224
       float cost;
+      bool using_footprint = false;
       unsigned x_i, y_i;
       if (!world_to_map(cm, o->tx[i * T + j], o->ty[i * T + j], x_i, y_i)) {
         cost = SMPC_COST_NO_INFORMATION;
       } else {
         cost = static_cast<float>(get_cost(cm, x_i, y_i));
+        if (p.consider_footprint &&
+          (cost >= possibly_inscribed_cost || possibly_inscribed_cost < 1.0f))
+        {
+          cost = static_cast<float>(footprint_cost_at_pose(
+              cm, o->tx[i * T + j], o->ty[i * T + j], o->tyaw[i * T + j]));
+          using_footprint = true;
+        }
       }
       if (cost < 1.0f) {continue;}
       // inCollision :185-201
@@ -607,7 +738,9 @@ void score_obstacles(smpc_oracle * o, const Tick & tk)
       float dist_to_obj = static_cast<float>(
         (static_cast<double>(scale_factor * min_radius) - std::log(static_cast<double>(cost)) +
         std::log(static_cast<double>(253.0f))) / static_cast<double>(scale_factor));
-      dist_to_obj -= min_radius;
+      if (!using_footprint) {
+        dist_to_obj -= min_radius;   // :106-108
+      }
       if (dist_to_obj < p.collision_margin_distance) {
         traj_cost += (p.collision_margin_distance - dist_to_obj);
       } else if (!near_goal) {
@@ -808,6 +941,8 @@ void score_cost(smpc_oracle * o, const Tick & tk)
   // :120-124
   const bool near_goal = within_position_goal_tolerance(
     p.near_goal_distance, tk.in->pose_x, tk.in->pose_y, tk.in->goal_x, tk.in->goal_y);
+  // :114-117,44 (possibly_inscribed_cost_ is refreshed when consider_footprint)
+  const float possibly_inscribed_cost_c = p.consider_footprint ? find_circumscribed_cost(cm) : 0.0f;
   std::vector<float> repulsive_cost(B, 0.0f);
   const size_t traj_len = T;
   bool all_trajectories_collide = true;
@@ -825,8 +960,15 @@ void score_cost(smpc_oracle * o, const Tick & tk)
       }
       if (pose_cost < 1.0f) {continue;}  // in free space
       // inCollision :175-201
+      float check_cost = pose_cost;
+      if (p.consider_footprint &&
+        (check_cost >= possibly_inscribed_cost_c || possibly_inscribed_cost_c < 1.0f))
+      {
+        check_cost = static_cast<float>(footprint_cost_at_pose(
+            cm, o->tx[i * T + j], o->ty[i * T + j], o->tyaw[i * T + j]));
+      }
       bool collide = false;
-      switch (static_cast<unsigned char>(pose_cost)) {
+      switch (static_cast<unsigned char>(check_cost)) {
         case SMPC_COST_LETHAL:
           collide = true;
           break;
@@ -1188,11 +1330,15 @@ int check_ready(smpc_oracle * o, const smpc_tick_in * in)
   if (in->path_len > 0 && (!in->path_x || !in->path_y || !in->path_yaw)) {
     return fail(o, SMPC_ERR_INVALID, "path arrays missing");
   }
-  if (!o->costmap.set && (o->critics.obstacles.enabled || !in->path_pts_valid)) {
+  if (!o->costmap.set &&
+    (o->critics.obstacles.enabled || o->critics.cost.enabled || !in->path_pts_valid))
+  {
     return fail(o, SMPC_ERR_STATE, "no costmap");
   }
-  if (o->critics.obstacles.consider_footprint) {
-    return fail(o, SMPC_ERR_UNSUPPORTED, "consider_footprint=true is out of scope");
+  if (((o->critics.obstacles.enabled && o->critics.obstacles.consider_footprint) ||
+    (o->critics.cost.enabled && o->critics.cost.consider_footprint)) && o->costmap.fp_x.empty())
+  {
+    return fail(o, SMPC_ERR_STATE, "consider_footprint=true needs a footprint (smpc_oracle_set_footprint)");
   }
   return SMPC_OK;
 }
@@ -1311,6 +1457,22 @@ int smpc_oracle_set_costmap(smpc_oracle * o, const uint8_t * cells, uint32_t wid
   c.cost_scaling_factor = cost_scaling_factor;
   c.inflation_radius = inflation_radius;
   c.set = true;
+  return SMPC_OK;
+}
+
+int smpc_oracle_set_footprint(smpc_oracle * o, const double * xy, uint32_t n_points,
+                              double circumscribed_radius, double layer_cost_scaling_factor)
+{
+  if (!o || (n_points && !xy)) {return SMPC_ERR_INVALID;}
+  Costmap & c = o->costmap;
+  c.fp_x.clear();
+  c.fp_y.clear();
+  for (uint32_t i = 0; i < n_points; ++i) {
+    c.fp_x.push_back(xy[2 * i]);
+    c.fp_y.push_back(xy[2 * i + 1]);
+  }
+  c.circumscribed_radius = circumscribed_radius;
+  c.layer_cost_scaling_factor = layer_cost_scaling_factor;
   return SMPC_OK;
 }
 

@@ -45,6 +45,8 @@ int smpc_oracle_set_costmap(smpc_oracle* o, const uint8_t* cells, uint32_t width
                             uint32_t height, double origin_x, double origin_y,
                             double resolution, int track_unknown, float inscribed_radius,
                             float cost_scaling_factor, float inflation_radius);
+int smpc_oracle_set_footprint(smpc_oracle* o, const double* xy, uint32_t n_points,
+                              double circumscribed_radius, double layer_cost_scaling_factor);
 int smpc_oracle_set_noise(smpc_oracle* o, const float* nvx, const float* nvy,
                           const float* nwz);
 int smpc_oracle_seed(smpc_oracle* o, uint64_t seed);

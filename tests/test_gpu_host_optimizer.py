@@ -47,8 +47,8 @@ def test_closed_loop_eval_control_matches_reference_host_logic():
 
 def test_closed_loop_with_the_deployed_critic_list():
     """robot_bringup/config/nav2_params.yaml:186-275: B 2000, T 56, the nine critics of its
-    `critics:` list with its weights (CostCritic in point mode: consider_footprint is out of
-    scope), closed loop against the reference host logic on the oracle."""
+    `critics:` list with its weights (CostCritic in point mode here; consider_footprint is
+    covered by test_gpu_parity.py::test_consider_footprint_parity), closed loop against the reference host logic on the oracle."""
     from mpcholonavigation_amd.host_optimizer import Optimizer
     from oracle.loader import OracleOptimizer
     names = ["ConstraintCritic", "CostCritic", "GoalCritic", "GoalAngleCritic", "PathAlignCritic",

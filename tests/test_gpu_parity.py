@@ -265,10 +265,12 @@ def test_error_paths(Smpc):
         g.optimize(scn.tick, scn.u0)
     assert e.value.code == A.SMPC_ERR_STATE
     cr = default_critics()
-    cr.obstacles.consider_footprint = 1
+    cr.obstacles.consider_footprint = 1      # accepted, but the tick needs a footprint
+    g.set_critics(cr)
+    g.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
     with pytest.raises(SmpcError) as e:
-        g.set_critics(cr)
-    assert e.value.code == A.SMPC_ERR_UNSUPPORTED
+        g.optimize(scn.tick, scn.u0)
+    assert e.value.code == A.SMPC_ERR_STATE
     with pytest.raises(SmpcError):           # trajectories were not requested
         g.get_generated_trajectories()
 
@@ -422,3 +424,64 @@ def test_huge_yaw_takes_the_checked_sincos(Smpc, Oracle, lane):
     assert og.non_colliding == oo.non_colliding
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
                   label=f"huge yaw lane={lane}")
+
+
+FOOTPRINT = np.array([[0.25, 0.18], [0.25, -0.18], [-0.25, -0.18], [-0.25, 0.18]])   # 0.5 x 0.36 m
+
+
+@pytest.mark.parametrize("names,fp_obs,fp_cost,B,T", [
+    (("cost", "path_follow", "prefer_forward"), False, True, 2000, 56),
+    (("obstacles", "path_align", "path_follow"), True, False, 2000, 56),
+    (DEPLOYED, False, True, 2000, 56),
+    (("obstacles", "goal", "twirling"), True, False, 1500, 40),
+    (("cost", "constraint", "velocity_deadband"), False, True, 1000, 64)])
+def test_consider_footprint_parity(Smpc, Oracle, names, fp_obs, fp_cost, B, T):
+    """consider_footprint = true (the deployed YAML sets it for CostCritic):
+    a rectangular footprint checked with nav2's footprintCostAtPose wherever the centre cost
+    reaches the possibly-inscribed cost; GPU general pass vs the oracle's restatement."""
+    from scipy import ndimage
+    cfg, scn, noise = make_case(B, T)
+    # a wall 0.35 m beside the path with nav2's inflation around it (inscribed 0.1 m,
+    # radius 0.55 m, scaling 10): sideways rollouts graze or hit it
+    res, t = scn.resolution, scn.tick
+    cells = np.zeros_like(scn.cells)
+    ix0, ix1 = int((t.pose_x + 0.3) / res), int((t.pose_x + 1.3) / res)
+    iy = int((t.pose_y + 0.35) / res)
+    cells[iy:iy + 2, ix0:ix1] = 254
+    d = ndimage.distance_transform_edt(cells != 254) * res
+    infl = np.where(d <= 0.1, 253, np.floor(252 * np.exp(-10.0 * (d - 0.1)))).astype(np.uint8)
+    infl[d > 0.55] = 0
+    cells = np.where(cells == 254, 254, infl).astype(np.uint8)
+    scn.cells = cells
+    cr = _extra_critics(names)
+    cr.obstacles.consider_footprint = int(fp_obs)
+    cr.cost.consider_footprint = int(fp_cost)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, critics=cr, noise=noise)
+        obj.set_footprint(FOOTPRINT, circumscribed_radius=float(np.hypot(0.25, 0.18)),
+                          layer_cost_scaling_factor=10.0)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert og.fail_flag == oo.fail_flag
+    assert og.non_colliding == oo.non_colliding
+    assert 0 < oo.non_colliding < B          # the footprint really decides some rollouts
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=3,
+                  label=f"footprint {names} obs={fp_obs} cost={fp_cost}")
+
+
+def test_consider_footprint_needs_a_footprint(Smpc):
+    cfg, scn, noise = make_case(256, 30)
+    cr = _extra_critics(("cost",))
+    cr.cost.consider_footprint = 1
+    g = Smpc(cfg)
+    configure(g, scn, critics=cr, noise=noise)
+    with pytest.raises(Exception, match="smpc_set_footprint"):
+        g.optimize(scn.tick, scn.u0)
+    # both collision critics + a footprint: refused (they would disagree on who collides)
+    cr = _extra_critics(("cost", "obstacles"))
+    cr.cost.consider_footprint = 1
+    g.set_critics(cr)
+    g.set_footprint(FOOTPRINT, 0.31, 10.0)
+    with pytest.raises(Exception, match="both ObstaclesCritic and CostCritic"):
+        g.optimize(scn.tick, scn.u0)
