@@ -160,6 +160,62 @@ def time_multi_query(n_ctx, B, T, map_size, steps, warmup):
             "note": "replicas only: independent contexts on their own streams, no exchange"}
 
 
+def cpu_baseline_all_cores(T, map_size, threads, budget_s=8.0, B=65536):
+    """The same CPU restatement on `threads` host threads: the batch sharded over them exactly as
+    over GPUs (furthest point -> max, per-shard tuples -> combine; the oracle's shard entry
+    points, ctypes releases the GIL).  The reference itself is single-threaded; this is what an
+    OpenMP build of it could at best reach on this host."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mpcholonavigation_amd.synthetic import make_noise, make_scenario
+    from mpcholonavigation_amd.tick import default_config, default_critics
+    from oracle.loader import Oracle
+    scn = make_scenario(T, map_size=map_size)
+    noise = make_noise(B, T)
+    per = B // threads
+    shards = []
+    for k in range(threads):
+        cfg = default_config(batch_size=per, time_steps=T, shard_offset=k * per, global_batch_size=per * threads)
+        o = Oracle(cfg, fast=True)
+        o.set_critics(default_critics())
+        o.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution,
+                      inscribed_radius=scn.inscribed_radius, cost_scaling_factor=scn.cost_scaling_factor,
+                      inflation_radius=scn.inflation_radius)
+        o.set_noise(*[n[k * per:(k + 1) * per] for n in noise])
+        shards.append(o)
+    pool = ThreadPoolExecutor(threads)
+
+    hint = [None]
+
+    def tick(u):
+        # the protocol of ShardedOptimizer: speculate on the previous tick's furthest point,
+        # re-score on a miss (one rollout per tick in the steady state)
+        if hint[0] is None:
+            hint[0] = int(max(pool.map(lambda o: o.shard_furthest(scn.tick, u), shards)))
+        tuples = np.stack(list(pool.map(lambda o: o.shard_score(scn.tick, u, hint[0]), shards)))
+        u_new, out = shards[0].shard_combine(tuples)
+        if out.furthest_valid and int(out.furthest_reached_path_point) != hint[0]:
+            hint[0] = int(out.furthest_reached_path_point)
+            tuples = np.stack(list(pool.map(lambda o: o.shard_score(scn.tick, u, hint[0]), shards)))
+            u_new, out = shards[0].shard_combine(tuples)
+        return u_new, out
+
+    u = scn.u0
+    u_new, _ = tick(u)
+    u = shift(u_new)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        u_new, _ = tick(u)
+        u = shift(u_new)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 400:
+            break
+    el = time.perf_counter() - t0
+    pool.shutdown()
+    return {"value": per * threads * n / el, "unit": "rollouts/s", "cores": threads,
+            "sample": f"{n} ticks of {per * threads} rollouts x {T} steps sharded over {threads} threads "
+                      "(furthest point speculated, re-scored on a miss)"}
+
+
 def cpu_baseline(T, map_size, budget_s=12.0, B=65536, max_ticks=200):
     """The CPU restatement built with the reference's flags, one thread
     (the reference is single-threaded: CMakeLists.txt:7-8), bounded sample."""
@@ -335,6 +391,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, MAP)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            nthr = max(1, min(32, (os.cpu_count() or 2) // 2))
+            line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(T, MAP, nthr)
             # configs[0], the reference's own CPU-runnable case (1000 x 30), on both sides
             c0 = cpu_baseline(30, MAP, budget_s=3.0, B=1000, max_ticks=2000)
             g0 = time_config(1000, 30, MAP, 400, 40)
