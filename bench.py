@@ -128,36 +128,30 @@ def time_config(B, T, map_size, steps, warmup):
 
 def time_multi_query(n_ctx, B, T, map_size, steps, warmup):
     """BASELINE configs[4] per GPU: n_ctx independent planning instances (replicas only: no
-    collective), one smpc_ctx, host thread and stream each, ticking concurrently."""
-    import threading
-    ctxs = [make_ctx(B, T, map_size, seed=1234 + i) for i in range(n_ctx)]
-    start, done = threading.Barrier(n_ctx + 1), threading.Barrier(n_ctx + 1)
-
-    def worker(g, scn):
-        u = scn.u0
-        for _ in range(warmup):
-            u_new, _ = g.optimize(scn.tick, u)
-            u = shift(u_new)
-        start.wait()
-        for _ in range(steps):
-            u_new, _ = g.optimize(scn.tick, u)
-            u = shift(u_new)
-        done.wait()
-
-    ths = [threading.Thread(target=worker, args=(g, scn)) for g, scn, _ in ctxs]
-    for t in ths:
-        t.start()
-    start.wait()
+    collective) ticked together by smpc_group_optimize — one upload, one scoring launch with the
+    instance as second grid dimension, one reduction launch."""
+    from mpcholonavigation_amd import _abi as A
+    from mpcholonavigation_amd.optimizer import SmpcGroup
+    ctxs = [make_ctx(B, T, map_size, seed=1234 + i, flags=A.SMPC_FLAG_LANE_PER_ROLLOUT)
+            for i in range(n_ctx)]
+    grp = SmpcGroup([g for g, _, _ in ctxs])
+    ticks = [scn.tick for _, scn, _ in ctxs]
+    us = [scn.u0 for _, scn, _ in ctxs]
+    for _ in range(warmup):
+        us = [shift(u) for u, _ in grp.optimize(ticks, us)]
     t0 = time.perf_counter()
-    done.wait()
+    for _ in range(steps):
+        res = grp.optimize(ticks, us)
+        us = [shift(u) for u, _ in res]
     el = time.perf_counter() - t0
-    for t in ths:
-        t.join()
+    passes = sum(o.passes for _, o in res) / n_ctx
+    grp.close()
     for g, _, _ in ctxs:
         g.close()
     return {"queries": n_ctx, "rollouts_per_query": B, "rollouts_per_s": n_ctx * B * steps / el,
-            "ms_per_tick_per_query": 1e3 * el / steps,
-            "note": "replicas only: independent contexts on their own streams, no exchange"}
+            "ms_per_round": 1e3 * el / steps, "passes_per_query": passes,
+            "note": "replicas only: independent contexts, no exchange; one batched launch per round "
+                    "(smpc_group_optimize)"}
 
 
 def cpu_baseline_all_cores(T, map_size, threads, budget_s=8.0, B=65536):

@@ -430,6 +430,24 @@ int smpc_shard_rescore_failed(smpc_ctx* ctx, float* d_tuple);
 int smpc_shard_combine(smpc_ctx* ctx, const float* d_tuples, uint32_t n_tuples,
                        float* u_out, smpc_tick_out* out);
 
+/* ---- several planning instances per launch (multi-robot fleets; BASELINE "multi-query") ----
+ * Independent contexts (own noise, costmap, critics, control sequence) on one GPU whose
+ * ticks are issued together: one upload, one scoring launch with the instance as the second
+ * grid dimension, one reduction launch.  Results are exactly those of smpc_optimize on each
+ * context; a member that cannot take the batched launch this tick (not on the
+ * lane-per-rollout pass — create members with SMPC_FLAG_LANE_PER_ROLLOUT —, first tick without a
+ * furthest-point guess, speculation miss, every rollout colliding, iteration_count > 1) is
+ * ticked on its own inside the call.  Members must share device and time_steps; while grouped,
+ * a context must not be used through smpc_optimize directly; destroy the group before its
+ * members.  Replaces N calls of Optimizer::optimize() [ref src/optimizer.cpp:157-164] by
+ * N controller instances. */
+typedef struct smpc_group smpc_group;
+int smpc_group_create(smpc_ctx* const* ctxs, uint32_t n, smpc_group** out);
+void smpc_group_destroy(smpc_group* group);
+/* ins[n], u_inout[n] (pointers to 3*T floats each), outs[n] (may be NULL) */
+int smpc_group_optimize(smpc_group* group, const smpc_tick_in* ins, float* const* u_inout,
+                        smpc_tick_out* outs);
+
 /* ---- the same tick with the exchanges inside the library (RCCL over xGMI) ----
  * One ncclComm per ctx, one call per tick: upload -> score -> ncclAllGather(tuples) ->
  * combine -> wait, all on the ctx's stream (speculate != 0: the furthest point of the

@@ -263,6 +263,10 @@ PROTOTYPES = {
     "smpc_shard_rescore_failed": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_shard_combine": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p,
                                      C.POINTER(SmpcTickOut)]),
+    "smpc_group_create": (C.c_int, [C.POINTER(_ctx), C.c_uint32, C.POINTER(_ctx)]),
+    "smpc_group_destroy": (None, [_ctx]),
+    "smpc_group_optimize": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.POINTER(C.c_void_p),
+                                      C.POINTER(SmpcTickOut)]),
     "smpc_shard_comm_id": (C.c_int, [C.c_void_p, C.c_uint32]),
     "smpc_shard_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "smpc_shard_tick": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p, C.POINTER(SmpcTickOut),

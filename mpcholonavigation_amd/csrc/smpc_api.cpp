@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,10 @@ uint32_t smpc_lane_block();
 hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu);
 hipError_t smpc_lane_set_lds_limit(int bytes);
 hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
+hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
+                                      const SmpcLds& L, uint32_t grid, hipStream_t st);
+hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
+                                   float neg_inv_temp, hipStream_t st);
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
 
 namespace {
@@ -151,6 +156,9 @@ struct smpc_ctx {
   bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
   uint32_t last_pass_kind = 0;
+  // member of a smpc_group: the group uploads every member's tick block in one copy
+  bool defer_upload = false;
+  uint32_t lane_window_bytes = 0;   // first LDS region of the lane pass this tick
   // consider_footprint: robot footprint (smpc_set_footprint) and the LUT pair built for it
   std::vector<double> fp_x, fp_y;
   double fp_circumscribed_radius = 0.0, fp_layer_scale = -1.0;
@@ -242,12 +250,12 @@ void free_ctx(smpc_ctx* c)
          c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
     if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
-  if (c->d_tick) (void)hipFree(c->d_tick);
+  if (c->d_tick && !c->defer_upload) (void)hipFree(c->d_tick);
   if (c->d_lut) (void)hipFree(c->d_lut);
   if (c->d_lut_fp) (void)hipFree(c->d_lut_fp);
   if (c->h_lut_fp) (void)hipHostFree(c->h_lut_fp);
   if (c->h_lut) (void)hipHostFree(c->h_lut);
-  if (c->h_tick) (void)hipHostFree(c->h_tick);
+  if (c->h_tick && !c->defer_upload) (void)hipHostFree(c->h_tick);   // (a group's slot is not ours)
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
   if (c->d_all) (void)hipFree(c->d_all);
@@ -282,6 +290,10 @@ TickLayout tick_layout(uint32_t T, uint32_t P)
 
 // LDS carve-up of the streaming pass.  nsamp = PathAlign samples per rollout (0: off).
 SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
+                 uint32_t nsamp);
+SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T);
+
+SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
                  uint32_t nsamp = 0)
 {
   SmpcLds L{};
@@ -309,6 +321,18 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
   o += nwave * L.scr_stride * 4;
   L.total = o;
   return L;
+}
+
+// LDS layout of the lane-per-rollout pass: window + the NO_INFORMATION byte + one scratch byte
+// per lane (cell_byte_exact), LUT, path, per wave the parked wz [64][68] + weights [64]
+SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T)
+{
+  const uint32_t lblock = smpc_lane_block();
+  SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
+                        window_bytes != 0, 0);
+  Lt.scr_stride = align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);
+  Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
+  return Lt;
 }
 
 // distanceToObstacle (obstacles_critic.cpp:99-112) for an 8-bit cost, point mode
@@ -514,20 +538,21 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
         init = j;
       }
     }
+    // :64-74 occupancy of the path between the initial and the furthest point.  The
+    // reference walks i = init..S-1 with a running count of invalid points and stops at the
+    // first i where count / range > ratio and count > 2; the count only grows and range is
+    // fixed per S, so that happens iff it holds for the final count: prefix sums, O(P).
+    std::vector<uint32_t> inval(P + 1, 0);
+    for (uint32_t i = 0; i < P; ++i) inval[i + 1] = inval[i] + ((i + 1 < P && !pvalid[i]) ? 1u : 0u);
     for (uint32_t S = 0; S < P; ++S) {
       bool on = S >= cr.path_align.offset_from_furthest;     // path_align_critic.cpp:58-61
-      if (on) {
-        // :64-74 occupancy of the path between the initial and the furthest point
-        unsigned int invalid_ctr = 0;
+      if (on && S > init) {
+        const unsigned int invalid_ctr = inval[S] - inval[init];
         const float range = static_cast<float>(static_cast<size_t>(S) - init);
-        for (size_t i = init; i < S; i++) {
-          if (!pvalid[i]) invalid_ctr++;
-          if (static_cast<float>(invalid_ctr) / range > cr.path_align.max_path_occupancy_ratio &&
-            invalid_ctr > 2)
-          {
-            on = false;
-            break;
-          }
+        if (static_cast<float>(invalid_ctr) / range > cr.path_align.max_path_occupancy_ratio &&
+          invalid_ctr > 2)
+        {
+          on = false;
         }
       }
       pa_active[S] = on ? 1 : 0;
@@ -621,7 +646,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   }
 
   if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev0, c->stream));
-  HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
+  if (!c->defer_upload)
+    HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
 
   // ---- kernel parameter block ------------------------------------------------------
   SmpcDev& d = c->dev;
@@ -763,13 +789,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
   c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
   if (c->lane_now) {
-    // lane-per-rollout pass: same staging area; per wave only the block-combine slot
-    const uint32_t lblock = smpc_lane_block();
-    // window + the NO_INFORMATION byte + one scratch byte per lane (cell_byte_exact)
-    SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
-                          window_bytes != 0, 0);
-    Lt.scr_stride = align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);   // parked wz + weights
-    Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
+    const SmpcLds Lt = lane_lds(window_bytes, P, T);
+    c->lane_window_bytes = window_bytes;
     c->lds_tpr = Lt;
     if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
   }
@@ -824,17 +845,37 @@ int launch_furthest(smpc_ctx* c, float* d_furthest)
 // finish_furthest: when `finish`, the reduction also produces the new control sequence
 // (single-GPU tick) and reports *finish_furthest (or the pass's own value) as the furthest
 // point the critics used
-int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
-                 uint32_t furthest_hint, float* d_tuple, bool finish = false,
-                 const float* finish_furthest = nullptr)
+// parameter blocks of one scoring pass + reduction of ctx c (no launch)
+void fill_score_args(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
+                     uint32_t furthest_hint, bool finish, const float* finish_furthest, SmpcDev& d,
+                     SmpcFinal& fin)
 {
-  SmpcDev d = c->dev;
+  d = c->dev;
   d.flags = flags;
   if (u_dev) d.u = u_dev;
   d.d_furthest = d_furthest;
   d.furthest_hint = furthest_hint;
   d.costs = c->d_costs[c->costs_cur];
   d.costs_prev = c->d_costs[c->costs_cur ^ 1];
+  fin = SmpcFinal{};
+  fin.enabled = finish ? 1 : 0;
+  fin.vx_max = c->c_vx_max; fin.vx_min = c->c_vx_min; fin.vy_max = c->c_vy; fin.wz_max = c->c_wz;
+  fin.u_dev = c->d_out; fin.u_host = c->h_out_dev; fin.furthest_used = finish_furthest;
+  if (finish && c->poll_enabled) {
+    fin.done_counter = reinterpret_cast<uint32_t*>(c->d_furthest) + 2;
+    fin.seq = ++c->seq;
+    if (fin.seq == 0) fin.seq = ++c->seq;
+    c->poll_seq = fin.seq;
+  }
+}
+
+int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
+                 uint32_t furthest_hint, float* d_tuple, bool finish = false,
+                 const float* finish_furthest = nullptr)
+{
+  SmpcDev d;
+  SmpcFinal fin;
+  fill_score_args(c, flags, u_dev, d_furthest, furthest_hint, finish, finish_furthest, d, fin);
   const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
   if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
   uint32_t nblk = c->grid;
@@ -850,16 +891,6 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   if (prof) {
     HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
     c->evp_used += 2;
-  }
-  SmpcFinal fin{};
-  fin.enabled = finish ? 1 : 0;
-  fin.vx_max = c->c_vx_max; fin.vx_min = c->c_vx_min; fin.vy_max = c->c_vy; fin.wz_max = c->c_wz;
-  fin.u_dev = c->d_out; fin.u_host = c->h_out_dev; fin.furthest_used = finish_furthest;
-  if (finish && c->poll_enabled) {
-    fin.done_counter = reinterpret_cast<uint32_t*>(c->d_furthest) + 2;
-    fin.seq = ++c->seq;
-    if (fin.seq == 0) fin.seq = ++c->seq;
-    c->poll_seq = fin.seq;
   }
   HIPCK(c, smpc_launch_reduce(c->d_partials, nblk, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
   c->passes++;
@@ -1635,6 +1666,208 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
     out->score_pass_ms = profile_pass_ms(c);
     out->pass_kind = c->last_pass_kind;
   }
+  return SMPC_OK;
+}
+
+// ---- several planning instances per launch (BASELINE configs[4]: multi-robot fleets) --------
+
+struct smpc_group {
+  std::vector<smpc_ctx*> ctxs;
+  std::vector<hipStream_t> saved_stream;
+  std::vector<uint8_t*> saved_h_tick, saved_d_tick;
+  uint8_t* h_all = nullptr;   // pinned: n tick blocks, then SmpcDev[n], SmpcReduceArgs[n]
+  uint8_t* d_all = nullptr;
+  size_t slot = 0, off_dev = 0, off_red = 0, total = 0;
+  hipStream_t stream = nullptr;
+  uint64_t batched_ticks = 0, single_ticks = 0;
+};
+
+int smpc_group_create(smpc_ctx* const* ctxs, uint32_t n, smpc_group** out)
+{
+  if (!ctxs || !n || !out) return fail(nullptr, SMPC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!ctxs[i]) return fail(nullptr, SMPC_ERR_INVALID, "null ctx");
+    if (ctxs[i]->device != ctxs[0]->device || ctxs[i]->cfg.time_steps != ctxs[0]->cfg.time_steps)
+      return fail(nullptr, SMPC_ERR_INVALID, "a group's contexts share the device and time_steps");
+    if (ctxs[i]->defer_upload) return fail(nullptr, SMPC_ERR_STATE, "ctx already in a group");
+  }
+  smpc_group* g = new (std::nothrow) smpc_group();
+  if (!g) return fail(nullptr, SMPC_ERR_NOMEM, "out of memory");
+  smpc_ctx* c0 = ctxs[0];
+  if (hipSetDevice(c0->device) != hipSuccess) {
+    delete g;
+    return fail(nullptr, SMPC_ERR_DEVICE, "hipSetDevice");
+  }
+  g->slot = align_up(static_cast<uint32_t>(c0->tick_cap), 256);
+  g->off_dev = g->slot * n;
+  g->off_red = g->off_dev + align_up(static_cast<uint32_t>(sizeof(SmpcDev)) * n, 256);
+  g->total = g->off_red + align_up(static_cast<uint32_t>(sizeof(SmpcReduceArgs)) * n, 256);
+  if (hipHostMalloc(&g->h_all, g->total, hipHostMallocDefault) != hipSuccess ||
+    hipMalloc(&g->d_all, g->total) != hipSuccess)
+  {
+    if (g->h_all) (void)hipHostFree(g->h_all);
+    delete g;
+    return fail(nullptr, SMPC_ERR_NOMEM, "group buffers");
+  }
+  g->stream = c0->own_stream;
+  for (uint32_t i = 0; i < n; ++i) {
+    smpc_ctx* c = ctxs[i];
+    (void)hipStreamSynchronize(c->stream);
+    g->ctxs.push_back(c);
+    g->saved_stream.push_back(c->stream);
+    g->saved_h_tick.push_back(c->h_tick);
+    g->saved_d_tick.push_back(c->d_tick);
+    c->stream = g->stream;
+    c->h_tick = g->h_all + g->slot * i;
+    c->d_tick = g->d_all + g->slot * i;
+    c->defer_upload = true;
+    c->lut_valid = false;
+  }
+  *out = g;
+  return SMPC_OK;
+}
+
+void smpc_group_destroy(smpc_group* g)
+{
+  if (!g) return;
+  (void)hipStreamSynchronize(g->stream);
+  for (size_t i = 0; i < g->ctxs.size(); ++i) {
+    smpc_ctx* c = g->ctxs[i];
+    c->stream = g->saved_stream[i];
+    c->h_tick = g->saved_h_tick[i];
+    c->d_tick = g->saved_d_tick[i];
+    c->defer_upload = false;
+  }
+  if (g->h_all) (void)hipHostFree(g->h_all);
+  if (g->d_all) (void)hipFree(g->d_all);
+  delete g;
+}
+
+// One tick of every member.  When every member can take the lane-per-rollout pass with a
+// speculated furthest point (the steady state), the group issues ONE upload, ONE scoring launch
+// (blockIdx.y = member) and ONE reduction launch; a member that misses its speculation, collides
+// everywhere, or is not eligible is ticked on its own with smpc_optimize — results are those of
+// smpc_optimize in every case.
+int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_inout,
+                        smpc_tick_out* outs)
+{
+  if (!g || !ins || !u_inout) return fail(nullptr, SMPC_ERR_INVALID, "null argument");
+  const uint32_t n = static_cast<uint32_t>(g->ctxs.size());
+  smpc_ctx* c0 = g->ctxs[0];
+  HIPCK(c0, hipSetDevice(c0->device));
+  auto single = [&](uint32_t i) -> int {
+    smpc_ctx* c = g->ctxs[i];
+    c->defer_upload = false;   // its own upload, into its slot of the group's buffers
+    const int rc = smpc_optimize(c, &ins[i], u_inout[i], outs ? &outs[i] : nullptr);
+    c->defer_upload = true;
+    g->single_ticks++;
+    return rc;
+  };
+  static const bool timing = getenv("SMPC_GROUP_TIMING") != nullptr;
+  auto now = [] {return std::chrono::steady_clock::now();};
+  auto us_between = [](auto a, auto b) {return std::chrono::duration<double, std::micro>(b - a).count();};
+  const auto t_start = now();
+  // ---- prepare every member; decide whether the batched launch applies -----------------
+  bool batched = true;
+  uint32_t Pmax = 0, window_bytes = 0, gridx = 0;
+  bool obst = false;
+  std::vector<uint32_t> flags(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    smpc_ctx* c = g->ctxs[i];
+    if (!u_inout[i]) return fail(c, SMPC_ERR_INVALID, "null control sequence");
+    c->passes = 0;
+    c->evp_used = 0;
+    c->costs_cur = 0;
+    int rc = prepare_tick(c, &ins[i], u_inout[i]);
+    if (rc != SMPC_OK) return rc;
+    flags[i] = scoring_flags(c, c->fail_in);
+    const bool need_f = (flags[i] & SD_NEED_FURTHEST) != 0;
+    if (need_f) flags[i] |= SD_LOCAL_FURTHEST;
+    const bool ok = c->lane_now && c->cfg.iteration_count == 1 && !c->fail_in &&
+      !(c->cfg.flags & (SMPC_FLAG_NO_SPECULATION | SMPC_FLAG_PROFILE)) && (!need_f || c->hint_valid) &&
+      c->poll_enabled;
+    if (!ok) batched = false;
+    if (i == 0) {
+      window_bytes = c->lane_window_bytes;
+      obst = (flags[i] & SD_OBSTACLES) != 0;
+    } else if (c->lane_window_bytes != window_bytes || ((flags[i] & SD_OBSTACLES) != 0) != obst) {
+      batched = false;
+    }
+    Pmax = std::max(Pmax, c->P);
+    gridx = std::max(gridx, c->grid_tpr);
+  }
+  const uint32_t T = c0->cfg.time_steps;
+  const SmpcLds L = lane_lds(window_bytes, Pmax, T);
+  if (L.total > kLdsPerCu) batched = false;
+  if (!batched) {
+    for (uint32_t i = 0; i < n; ++i) {
+      const int rc = single(i);
+      if (rc != SMPC_OK) return rc;
+    }
+    return SMPC_OK;
+  }
+  const auto t_prep = now();
+  // ---- one upload, one scoring launch, one reduction launch ---------------------------------
+  SmpcDev* hd = reinterpret_cast<SmpcDev*>(g->h_all + g->off_dev);
+  SmpcReduceArgs* hr = reinterpret_cast<SmpcReduceArgs*>(g->h_all + g->off_red);
+  for (uint32_t i = 0; i < n; ++i) {
+    smpc_ctx* c = g->ctxs[i];
+    SmpcFinal fin;
+    fill_score_args(c, flags[i], nullptr, nullptr, c->hint, true, nullptr, hd[i], fin);
+    hr[i].partials = c->d_partials;
+    hr[i].tuple = c->d_tuple;
+    hr[i].nblk = gridx;
+    hr[i].host_out = fin.u_host;
+    hr[i].seq = fin.seq;
+    fin.u_host = nullptr;          // one publishing block for the whole group instead
+    fin.done_counter = nullptr;
+    hr[i].fin = fin;
+    c->passes++;
+    c->last_pass_kind = 1;
+  }
+  HIPCK(c0, hipMemcpyAsync(g->d_all, g->h_all, g->total, hipMemcpyHostToDevice, g->stream));
+  HIPCK(c0, smpc_launch_pass_lane_many(reinterpret_cast<const SmpcDev*>(g->d_all + g->off_dev), n,
+                                       T == 64, obst, L, gridx, g->stream));
+  HIPCK(c0, smpc_launch_reduce_many(reinterpret_cast<const SmpcReduceArgs*>(g->d_all + g->off_red), n,
+                                    T, c0->dev.neg_inv_temp, g->stream));
+  g->batched_ticks++;
+  const auto t_launch = now();
+  // ---- per member: wait, verify the speculation and the collision count --------------------
+  for (uint32_t i = 0; i < n; ++i) {
+    smpc_ctx* c = g->ctxs[i];
+    int rc = fetch_out(c);
+    if (rc != SMPC_OK) return rc;
+    const bool need_f = (flags[i] & SD_NEED_FURTHEST) != 0;
+    const uint32_t S_true = static_cast<uint32_t>(c->h_out[3 * T + 2]);
+    const bool miss = need_f && S_true != c->hint;
+    const bool all_collide = (flags[i] & (SD_OBSTACLES | SD_COST)) && c->h_out[3 * T + 3] == 0.0f;
+    if (miss || all_collide) {
+      if (miss) {
+        c->spec_misses++;
+        c->hint = S_true;   // smpc_optimize speculates with the true value now: one pass
+      }
+      rc = single(i);
+      if (rc != SMPC_OK) return rc;
+      continue;
+    }
+    memcpy(u_inout[i], c->h_out, 3 * T * sizeof(float));
+    if (outs) {
+      smpc_tick_out* o = &outs[i];
+      memset(o, 0, sizeof(*o));
+      o->furthest_valid = need_f ? 1 : 0;
+      o->furthest_reached_path_point = need_f ? S_true : 0;
+      o->non_colliding = static_cast<uint32_t>(c->h_out[3 * T + 3]);
+      o->min_cost = c->h_out[3 * T + 0];
+      o->sum_w = c->h_out[3 * T + 1];
+      o->passes = c->passes;
+      o->pass_kind = 1;
+    }
+  }
+  if (timing && (g->batched_ticks % 64) == 0)
+    fprintf(stderr, "[smpc_group] prepare %.1f us, fill+launch %.1f us, wait+collect %.1f us; batched %llu single %llu\n",
+            us_between(t_start, t_prep), us_between(t_prep, t_launch), us_between(t_launch, now()),
+            (unsigned long long)g->batched_ticks, (unsigned long long)g->single_ticks);
   return SMPC_OK;
 }
 

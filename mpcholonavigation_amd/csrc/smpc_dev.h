@@ -139,6 +139,16 @@ struct SmpcFinal {
   uint32_t seq;                            // tick sequence number published at u_host[3T+7]
 };
 
+// one planning instance's arguments of smpc_reduce_partials_many
+struct SmpcReduceArgs {
+  const float* partials;
+  float* tuple;
+  uint32_t nblk;
+  SmpcFinal fin;       // u_host and done_counter null: smpc_publish_many reports to the host
+  float* host_out;     // the instance's host-mapped result mirror [3T + 8]
+  uint32_t seq;        // sequence number published at host_out[3T + 7]
+};
+
 // LDS carve-up, computed once on the host and passed to the kernel.
 struct SmpcLds {
   uint32_t off_lut, off_px, off_py, off_pyaw, off_D, off_valid, off_scr;

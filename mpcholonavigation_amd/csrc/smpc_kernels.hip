@@ -1001,11 +1001,9 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
 // With fin.enabled (single-GPU tick, one tuple) every block also finishes its columns:
 // divide by sum w, clip, write the new control sequence to device AND host-mapped memory
 // (optimizer.cpp:382-393,237-249) — the separate combine launch and the D2H copy go away.
-__global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __restrict__ partials,
-                                                            uint32_t nblk, uint32_t T,
-                                                            float neg_inv_temp,
-                                                            float* __restrict__ tuple,
-                                                            const SmpcFinal fin)
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ partials,
+                                                     uint32_t nblk, uint32_t T, float neg_inv_temp,
+                                                     float* __restrict__ tuple, const SmpcFinal& fin)
 {
   __shared__ float s_red[16], s_red2[16], s_red3[16];
   __shared__ float s_sc[2048];
@@ -1100,13 +1098,13 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
         else if (i < 2 * T) v2 = fminf(fmaxf(v2, -fin.vy_max), fin.vy_max);
         else v2 = fminf(fmaxf(v2, -fin.wz_max), fin.wz_max);
         fin.u_dev[i] = v2;
-        fin.u_host[i] = v2;
+        if (fin.u_host) fin.u_host[i] = v2;
       } else if (col == 0) {
         const float used = fin.furthest_used ? *fin.furthest_used : fu;
         const float res[5] = {m, sw, fu, nc, used};
         for (int k = 0; k < 5; ++k) {
           fin.u_dev[3 * T + k] = res[k];
-          fin.u_host[3 * T + k] = res[k];
+          if (fin.u_host) fin.u_host[3 * T + k] = res[k];
         }
       }
     }
@@ -1126,6 +1124,24 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
       }
     }
   }
+}
+
+
+__global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __restrict__ partials,
+                                                            uint32_t nblk, uint32_t T,
+                                                            float neg_inv_temp,
+                                                            float* __restrict__ tuple,
+                                                            const SmpcFinal fin)
+{
+  reduce_partials_body(partials, nblk, T, neg_inv_temp, tuple, fin);
+}
+
+// several planning instances in one launch (smpc_group_optimize): blockIdx.y picks the instance
+__global__ void __launch_bounds__(1024) smpc_reduce_partials_many(const SmpcReduceArgs* __restrict__ many,
+                                                                 uint32_t T, float neg_inv_temp)
+{
+  const SmpcReduceArgs& a = many[blockIdx.y];
+  reduce_partials_body(a.partials, a.nblk, T, neg_inv_temp, a.tuple, a.fin);
 }
 
 // ---------------------------------------------------------------------------
@@ -1322,6 +1338,34 @@ hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
   const uint32_t TL = 4 + 3 * T;
   hipLaunchKernelGGL(smpc_reduce_partials, dim3((TL + 31) / 32), dim3(1024), 0, st, partials, nblk,
                      T, neg_inv_temp, tuple, fin);
+  return hipGetLastError();
+}
+
+// After smpc_reduce_partials_many: ONE block copies every instance's result (3T + 8 floats) to its
+// host-mapped mirror and publishes the sequence words behind a single system-scope fence
+// (hundreds of blocks fencing PCIe writes one by one cost far more than the reduction itself).
+__global__ void __launch_bounds__(1024) smpc_publish_many(const SmpcReduceArgs* __restrict__ many,
+                                                         uint32_t n, uint32_t T)
+{
+  const uint32_t len = 3 * T + 5;
+  for (uint32_t i = threadIdx.x; i < n * len; i += blockDim.x) {
+    const uint32_t q = i / len, k = i - q * len;
+    many[q].host_out[k] = many[q].fin.u_dev[k];
+  }
+  __threadfence_system();
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < n; q += blockDim.x)
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(many[q].host_out + 3 * T + 7), many[q].seq,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
+                                   float neg_inv_temp, hipStream_t st)
+{
+  const uint32_t TL = 4 + 3 * T;
+  hipLaunchKernelGGL(smpc_reduce_partials_many, dim3((TL + 31) / 32, n), dim3(1024), 0, st, d_many, T,
+                     neg_inv_temp);
+  hipLaunchKernelGGL(smpc_publish_many, dim3(1), dim3(1024), 0, st, d_many, n, T);
   return hipGetLastError();
 }
 

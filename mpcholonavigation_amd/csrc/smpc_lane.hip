@@ -208,9 +208,13 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // The pass
 // ---------------------------------------------------------------------------
 // FULL: T == 64, every parked register is written by every group; OBST: ObstaclesCritic scored
-template <bool FULL, bool OBST>
-__global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p, const SmpcLds L)
+// MANY: several planning instances in one launch (smpc_group_optimize): blockIdx.y picks
+// the instance, whose parameter block comes from device memory instead of the kernel arguments
+template <bool FULL, bool OBST, bool MANY>
+__global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0, const SmpcLds L,
+                                                                const SmpcDev* __restrict__ many)
 {
+  const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
@@ -679,7 +683,25 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
 {
   const bool full = p.T == 64u, obst = (p.flags & SD_OBSTACLES) != 0;
 #define SMPC_LANE_LAUNCH(F, O) \
-  hipLaunchKernelGGL((smpc_pass_lane<F, O>), dim3(grid), dim3(LANE_BLOCK), L.total, st, p, L)
+  hipLaunchKernelGGL((smpc_pass_lane<F, O, false>), dim3(grid), dim3(LANE_BLOCK), L.total, st, p, L, \
+                     static_cast<const SmpcDev*>(nullptr))
+  if (full && obst) SMPC_LANE_LAUNCH(true, true);
+  else if (full) SMPC_LANE_LAUNCH(true, false);
+  else if (obst) SMPC_LANE_LAUNCH(false, true);
+  else SMPC_LANE_LAUNCH(false, false);
+#undef SMPC_LANE_LAUNCH
+  return hipGetLastError();
+}
+
+// n planning instances (same T, same critic set) in one launch; d_many: their parameter
+// blocks in device memory
+hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
+                                      const SmpcLds& L, uint32_t grid, hipStream_t st)
+{
+  const SmpcDev none{};
+#define SMPC_LANE_LAUNCH(F, O) \
+  hipLaunchKernelGGL((smpc_pass_lane<F, O, true>), dim3(grid, n), dim3(LANE_BLOCK), L.total, st, none, L, \
+                     d_many)
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
   else if (obst) SMPC_LANE_LAUNCH(false, true);
@@ -690,25 +712,30 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
 
 uint32_t smpc_lane_block() {return LANE_BLOCK;}
 
-static const void* lane_kernel(bool full, bool obst)
+static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY
 {
-  if (full) return obst ? reinterpret_cast<const void*>(&smpc_pass_lane<true, true>)
-                        : reinterpret_cast<const void*>(&smpc_pass_lane<true, false>);
-  return obst ? reinterpret_cast<const void*>(&smpc_pass_lane<false, true>)
-              : reinterpret_cast<const void*>(&smpc_pass_lane<false, false>);
+  switch (k & 7) {
+    case 0: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, false>);
+    case 1: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, false>);
+    case 2: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false>);
+    case 3: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false>);
+    case 4: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, true>);
+    case 5: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, true>);
+    case 6: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, true>);
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, true>);
+  }
 }
 
 hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu)
 {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lane_kernel(full, true),
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lane_kernel((full ? 1 : 0) | 2),
                                                       LANE_BLOCK, lds_bytes);
 }
 
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 4 && e == hipSuccess; ++k)
-    e = hipFuncSetAttribute(lane_kernel(k & 1, k & 2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            bytes);
+  for (int k = 0; k < 8 && e == hipSuccess; ++k)
+    e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }

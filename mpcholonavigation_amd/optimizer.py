@@ -217,3 +217,49 @@ class Smpc:
         self._ck(self.lib.smpc_shard_combine(self.h, C.c_void_p(d_tuples), n_tuples, _ptr(u),
                                              C.byref(out)))
         return u, out
+
+
+class SmpcGroup:
+    """Several Smpc contexts ticked with one launch (include/smpc.h: smpc_group_*)."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        self.lib = self.members[0].lib
+        n = len(self.members)
+        arr = (A._ctx * n)(*[m.h for m in self.members])
+        h = A._ctx()
+        rc = self.lib.smpc_group_create(arr, n, C.byref(h))
+        if rc != 0:
+            raise SmpcError(rc, self.lib.smpc_last_error(None).decode())
+        self.h = h
+
+    def optimize(self, ticks, us):
+        """ticks, us: one per member; returns [(u_new, SmpcTickOut)] in member order.
+        Passing the same `ticks` list object again reuses its C structs."""
+        n = len(self.members)
+        if getattr(self, "_ticks", None) is not ticks:
+            self._ticks = ticks
+            self._ins = (A.SmpcTickIn * n)(*[t.c for t in ticks])
+            self._bufs = np.empty((n, 3, self.members[0].T), np.float32)
+            self._ptrs = (C.c_void_p * n)(*[self._bufs[i].ctypes.data for i in range(n)])
+            self._outs = (A.SmpcTickOut * n)()
+        for i, u in enumerate(us):
+            self._bufs[i] = u
+        rc = self.lib.smpc_group_optimize(self.h, self._ins, self._ptrs, self._outs)
+        if rc != 0:
+            msg = next((m.lib.smpc_last_error(m.h).decode() for m in self.members
+                        if m.lib.smpc_last_error(m.h)), "")
+            raise SmpcError(rc, msg)
+        res = self._bufs.copy()
+        return [(res[i], A.SmpcTickOut.from_buffer_copy(self._outs[i])) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.lib.smpc_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

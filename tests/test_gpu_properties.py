@@ -246,3 +246,54 @@ def test_multi_query_contexts_are_independent():
         assert np.array_equal(ua, uc)
     for g in ctxs:
         g.close()
+
+
+def test_grouped_contexts_tick_in_one_launch():
+    """smpc_group_optimize (multi-robot fleets): members with different maps, paths (lengths
+    40..60), noise and control sequences give bit-for-bit what smpc_optimize gives each of them,
+    over a closed loop of ticks, and the steady state really is the batched launch."""
+    from mpcholonavigation_amd.optimizer import Smpc, SmpcGroup
+    from tests.helpers import configure
+    n, B, T = 5, 2048, 56
+    cases = []
+    for i in range(n):
+        cfg = default_config(batch_size=B, time_steps=T, flags=A.SMPC_FLAG_LANE_PER_ROLLOUT)
+        scn = make_scenario(T, seed=60 + i, path_points=40 + 5 * i)
+        noise = make_noise(B, T, seed=900 + i)
+        cases.append((cfg, scn, noise))
+
+    def fresh():
+        out = []
+        for cfg, scn, noise in cases:
+            g = Smpc(cfg)
+            configure(g, scn, noise=noise)
+            out.append(g)
+        return out
+
+    alone, grouped = fresh(), fresh()
+    grp = SmpcGroup(grouped)
+    us_a = [scn.u0 for _, scn, _ in cases]
+    us_g = [scn.u0 for _, scn, _ in cases]
+    kinds = []
+    for k in range(5):
+        ticks = []
+        for i, (cfg, scn, noise) in enumerate(cases):
+            t = scn.tick
+            ticks.append(Tick(t.pose_x + 0.02 * k, t.pose_y, t.pose_yaw, (0.3, 0.0, 0.0), t.path_x, t.path_y,
+                              t.path_yaw, t.goal_x, t.goal_y))
+        res_g = grp.optimize(ticks, us_g)
+        for i in range(n):
+            ua, oa = alone[i].optimize(ticks[i], us_a[i])
+            ug, og = res_g[i]
+            assert np.array_equal(ua, ug), (k, i)
+            assert oa.furthest_reached_path_point == og.furthest_reached_path_point
+            assert oa.non_colliding == og.non_colliding
+            assert og.pass_kind == 1
+            us_a[i] = np.concatenate([ua[:, 1:], ua[:, -1:]], axis=1)
+            us_g[i] = np.concatenate([ug[:, 1:], ug[:, -1:]], axis=1)
+        kinds.append([o.passes for _, o in res_g])
+    # after the first tick (no furthest-point guess yet) every member rides the batched launch
+    assert all(p == 1 for p in kinds[-1])
+    grp.close()
+    for g in alone + grouped:
+        g.close()
