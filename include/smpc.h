@@ -55,9 +55,18 @@ extern "C" {
 #define SMPC_COST_INSCRIBED 253
 #define SMPC_COST_FREE 0
 
-/* ---- motion models [ref include/.../motion_models.hpp:85-171].
- *      Only the holonomic Omni model is on the hot path (north star).      */
+/* ---- motion models [ref include/.../motion_models.hpp:85-171,
+ *      src/optimizer.cpp:414-426 setMotionModel].  Omni is the holonomic
+ *      model the north star names.  The two non-holonomic models draw no vy
+ *      noise, keep state.vy and control_sequence.vy at zero and return a Twist
+ *      without linear.y [ref src/optimizer.cpp:220-224,241-243,264-266,
+ *      334-337,374-389,404-410; src/noise_generator.cpp:117-121]; Ackermann
+ *      also bounds the turning radius of the updated control sequence
+ *      [ref motion_models.hpp:110-117] and adds a ConstraintCritic term
+ *      [ref src/critics/constraint_critic.cpp:54-69].                       */
 #define SMPC_MODEL_OMNI 0
+#define SMPC_MODEL_DIFF_DRIVE 1
+#define SMPC_MODEL_ACKERMANN 2
 
 /* ---- smpc_config.flags ------------------------------------------------- */
 #define SMPC_FLAG_STORE_TRAJECTORIES 0x1u /* materialise x,y,yaw [B,T] each
@@ -83,7 +92,7 @@ typedef struct smpc_config {
   uint32_t batch_size;      /* B, this ctx's rollouts (a shard when sharded) */
   uint32_t time_steps;      /* T                                             */
   uint32_t iteration_count; /* optimize() iterations per tick                */
-  uint32_t motion_model;    /* SMPC_MODEL_OMNI                               */
+  uint32_t motion_model;    /* SMPC_MODEL_*                                  */
   float model_dt;
   float temperature;
   float gamma;
@@ -96,6 +105,10 @@ typedef struct smpc_config {
    * global_batch_size rollouts.  0/0 means "not sharded". */
   uint64_t shard_offset;
   uint64_t global_batch_size;
+  /* AckermannConstraints.min_turning_r [ref motion_models.hpp:91-95],
+   * default 0.2; read only when motion_model == SMPC_MODEL_ACKERMANN. */
+  float ackermann_min_turning_r;
+  uint32_t reserved0;
 } smpc_config;
 
 /*

@@ -21,6 +21,8 @@ SMPC_COST_INSCRIBED = 253
 SMPC_COST_FREE = 0
 
 SMPC_MODEL_OMNI = 0
+SMPC_MODEL_DIFF_DRIVE = 1
+SMPC_MODEL_ACKERMANN = 2
 
 SMPC_FLAG_STORE_TRAJECTORIES = 0x1
 SMPC_FLAG_NO_SPECULATION = 0x2
@@ -52,6 +54,8 @@ class SmpcConfig(C.Structure):
         ("flags", C.c_uint32),
         ("shard_offset", C.c_uint64),
         ("global_batch_size", C.c_uint64),
+        ("ackermann_min_turning_r", C.c_float),
+        ("reserved0", C.c_uint32),
     ]
 
 

@@ -39,6 +39,8 @@ hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, floa
                                float* host_out, uint32_t seq, hipStream_t st);
 hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
+hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float min_r, uint32_t seq,
+                                 hipStream_t st);
 
 hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
 hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st);
@@ -222,6 +224,14 @@ struct smpc_ctx {
   uint64_t spec_misses = 0;
   // completion polling on the host-mapped result (SMPC_NO_POLL=1 disables)
   bool poll_enabled = true;
+  // Optimizer::isHolonomic (optimizer.cpp:235).  A non-holonomic model is the Omni data path
+  // with the vy noise, control_sequence.vy and state.vy[:,0] all zero: then state.vy = 0,
+  // dx = vx cos - 0 sin, the vy gamma term and the weighted vy update are exactly 0 — what the
+  // reference's isHolonomic() branches compute (optimizer.cpp:220-224,241-243,264-266,334-337,
+  // 374-389), without a second set of kernels.
+  bool holonomic = true;
+  float acker_r = -1.f;      // Ackermann min_turning_r, < 0 for the other models
+  uint32_t acker_seq = 0;    // completion word the Ackermann launch publishes this tick
   uint32_t seq = 0, poll_seq = 0;
   std::string err;
 };
@@ -412,6 +422,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   if (tl.total > c->tick_cap) return fail(c, SMPC_ERR_INVALID, "tick block overflow");
   uint8_t* h = c->h_tick;
   memcpy(h + tl.u, u_in, 3 * T * sizeof(float));
+  if (!c->holonomic) memset(h + tl.u + T * sizeof(float), 0, T * sizeof(float));
   float* px = reinterpret_cast<float*>(h + tl.px);
   float* py = reinterpret_cast<float*>(h + tl.py);
   float* pyaw = reinterpret_cast<float*>(h + tl.pyaw);
@@ -511,7 +522,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   const float yaw0 = in->pose_yaw;
   const float cos0 = cosf(yaw0), sin0 = sinf(yaw0);
   const float svx = static_cast<float>(in->speed_vx);
-  const float svy = static_cast<float>(in->speed_vy);
+  // state.vy[:,0] = speed.linear.y only if holonomic (optimizer.cpp:264-266)
+  const float svy = c->holonomic ? static_cast<float>(in->speed_vy) : 0.f;
   const float swz = static_cast<float>(in->speed_wz);
   const float dt = c->cfg.model_dt;
   // trajectories(0,0): first rollout point, identical for every rollout because
@@ -700,6 +712,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     const float min_sgn = cr.constraint.vx_min > 0.0f ? 1.0f : -1.0f;
     d.con_max_vel = sqrtf(cr.constraint.vx_max * cr.constraint.vx_max + cr.constraint.vy_max * cr.constraint.vy_max);
     d.con_min_vel = min_sgn * sqrtf(cr.constraint.vx_min * cr.constraint.vx_min + cr.constraint.vy_max * cr.constraint.vy_max);
+    d.con_acker_r = c->acker_r;
   }
   d.lut_cost = reinterpret_cast<const float*>(c->d_tick + tl.lut_cost);
   d.cost_w254 = cr.cost.cost_weight / 254.0f;   // cost_critic.cpp:34
@@ -711,7 +724,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.pang_weight = cr.path_angle.cost_weight; d.pang_power = cr.path_angle.cost_power;
   d.pang_offset = cr.path_angle.offset_from_furthest; d.pang_correct = pang_correct ? 1 : 0;
   d.db_vx = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[0]));
-  d.db_vy = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[1]));
+  // no vy term for a non-holonomic model (velocity_deadband_critic.cpp:78-97); with
+  // state.vy = 0 a zero deadband contributes max(0 - 0, 0) = 0
+  d.db_vy = c->holonomic ? std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[1])) : 0.0;
   d.db_wz = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[2]));
   d.db_weight = cr.velocity_deadband.cost_weight; d.db_power = cr.velocity_deadband.cost_power;
   d.lut_fp = c->d_lut_fp;
@@ -742,7 +757,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     d.fp_pic = static_cast<float>(result);
   }
   d.g_vx = c->cfg.gamma / powf(c->cfg.vx_std, 2);
-  d.g_vy = c->cfg.gamma / powf(c->cfg.vy_std, 2);
+  d.g_vy = c->holonomic ? c->cfg.gamma / powf(c->cfg.vy_std, 2) : 0.f;   // optimizer.cpp:374-380
   d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
   d.neg_inv_temp = -1 / c->cfg.temperature;
   d.k2 = d.neg_inv_temp * 1.4426950408889634f;
@@ -867,6 +882,11 @@ void fill_score_args(smpc_ctx* c, uint32_t flags, const float* u_dev, const floa
     if (fin.seq == 0) fin.seq = ++c->seq;
     c->poll_seq = fin.seq;
   }
+  if (finish && c->acker_r >= 0.f) {   // the Ackermann launch behind the reduction publishes
+    c->acker_seq = fin.seq;
+    fin.done_counter = nullptr;
+    fin.seq = 0;
+  }
 }
 
 int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
@@ -893,6 +913,8 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
     c->evp_used += 2;
   }
   HIPCK(c, smpc_launch_reduce(c->d_partials, nblk, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
+  if (finish && c->acker_r >= 0.f)
+    HIPCK(c, smpc_launch_ackermann(c->d_out, c->h_out_dev, d.T, c->acker_r, c->acker_seq, c->stream));
   c->passes++;
   return SMPC_OK;
 }
@@ -906,10 +928,25 @@ int launch_combine(smpc_ctx* c, const float* d_tuples, uint32_t n, const float* 
     if (seq == 0) seq = ++c->seq;
     c->poll_seq = seq;
   }
+  const bool acker = c->acker_r >= 0.f;
   HIPCK(c, smpc_launch_combine(d_tuples, n, T, c->dev.neg_inv_temp, c->c_vx_max, c->c_vx_min,
                                c->c_vy, c->c_wz, c->d_out, c->d_out + 3 * T, d_furthest_used,
-                               c->h_out_dev, seq, c->stream));
+                               c->h_out_dev, acker ? 0u : seq, c->stream));
+  if (acker) HIPCK(c, smpc_launch_ackermann(c->d_out, c->h_out_dev, T, c->acker_r, seq, c->stream));
   return SMPC_OK;
+}
+
+// control_sequence_.vy is never written for a non-holonomic model (optimizer.cpp:387-389):
+// the caller's row stays as it was
+void store_control_sequence(const smpc_ctx* c, float* u_inout)
+{
+  const uint32_t T = c->cfg.time_steps;
+  if (c->holonomic) {
+    memcpy(u_inout, c->h_out, 3 * T * sizeof(float));
+    return;
+  }
+  memcpy(u_inout, c->h_out, T * sizeof(float));
+  memcpy(u_inout + 2 * T, c->h_out + 2 * T, T * sizeof(float));
 }
 
 int fetch_out(smpc_ctx* c)
@@ -982,7 +1019,9 @@ int draw_noise(smpc_ctx* c)
   // draw order vx, wz, vy (noise_generator.cpp:107-122)
   HIPCK(c, smpc_launch_fill_noise(c->d_nvx, n, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
   HIPCK(c, smpc_launch_fill_noise(c->d_nwz, n, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
-  HIPCK(c, smpc_launch_fill_noise(c->d_nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
+  // noises_vy_ keeps its zeros for a non-holonomic model (noise_generator.cpp:117-121)
+  if (c->holonomic)
+    HIPCK(c, smpc_launch_fill_noise(c->d_nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
   int rc = update_time_major(c);
   if (rc != SMPC_OK) return rc;
   HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1012,6 +1051,7 @@ void smpc_config_default(smpc_config* c)
   c->vy_std = 0.2f;
   c->wz_std = 0.4f;
   c->device = -1;
+  c->ackermann_min_turning_r = 0.2f;   // ref motion_models.hpp:94
 }
 
 void smpc_critic_params_default(smpc_critic_params* p)
@@ -1049,8 +1089,10 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   *out = nullptr;
   if (cfg->batch_size == 0 || cfg->time_steps == 0 || cfg->iteration_count == 0)
     return fail(nullptr, SMPC_ERR_INVALID, "batch_size, time_steps, iteration_count must be > 0");
-  if (cfg->motion_model != SMPC_MODEL_OMNI)
-    return fail(nullptr, SMPC_ERR_UNSUPPORTED, "only the Omni (holonomic) motion model is in scope");
+  if (cfg->motion_model > SMPC_MODEL_ACKERMANN)
+    return fail(nullptr, SMPC_ERR_UNSUPPORTED, "motion_model must be Omni, DiffDrive or Ackermann");
+  if (cfg->motion_model == SMPC_MODEL_ACKERMANN && !(cfg->ackermann_min_turning_r >= 0.f))
+    return fail(nullptr, SMPC_ERR_INVALID, "ackermann_min_turning_r must be >= 0");
   if (cfg->time_steps > 64 * SMPC_MAX_R)
     return fail(nullptr, SMPC_ERR_UNSUPPORTED, "time_steps > 256");
   if (!(cfg->temperature > 0.f) || !(cfg->model_dt > 0.f))
@@ -1065,6 +1107,8 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   if (!c) return fail(nullptr, SMPC_ERR_NOMEM, "out of host memory");
   c->cfg = *cfg;
   smpc_critic_params_default(&c->critics);
+  c->holonomic = cfg->motion_model == SMPC_MODEL_OMNI;
+  c->acker_r = cfg->motion_model == SMPC_MODEL_ACKERMANN ? cfg->ackermann_min_turning_r : -1.f;
   c->c_vx_max = cfg->vx_max; c->c_vx_min = cfg->vx_min; c->c_vy = cfg->vy_max; c->c_wz = cfg->wz_max;
   int dev = cfg->device;
   if (dev < 0) {
@@ -1095,6 +1139,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   const size_t n = static_cast<size_t>(cfg->batch_size) * T * sizeof(float);
   CK(hipMalloc(&c->d_nvx, n));
   CK(hipMalloc(&c->d_nvy, n));
+  if (!c->holonomic) CK(hipMemset(c->d_nvy, 0, n));   // noises_vy_ (noise_generator.cpp:76-91)
   CK(hipMalloc(&c->d_nwz, n));
   {
     // which streaming pass: a wave per rollout (latency, small batches) or a lane per
@@ -1237,7 +1282,7 @@ int smpc_set_noise(smpc_ctx* c, const float* nvx, const float* nvy, const float*
   HIPCK(c, hipSetDevice(c->device));
   const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
   HIPCK(c, hipMemcpyAsync(c->d_nvx, nvx, n, hipMemcpyHostToDevice, c->stream));
-  HIPCK(c, hipMemcpyAsync(c->d_nvy, nvy, n, hipMemcpyHostToDevice, c->stream));
+  if (c->holonomic) HIPCK(c, hipMemcpyAsync(c->d_nvy, nvy, n, hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipMemcpyAsync(c->d_nwz, nwz, n, hipMemcpyHostToDevice, c->stream));
   {
     int rc = update_time_major(c);
@@ -1378,7 +1423,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     c->hint = S_host;
     c->hint_valid = true;
   }
-  memcpy(u_inout, c->h_out, 3 * T * sizeof(float));
+  store_control_sequence(c, u_inout);
   if (out) {
     memset(out, 0, sizeof(*out));
     out->fail_flag = fail_flag ? 1 : 0;
@@ -1653,7 +1698,7 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
     if (rc == SMPC_OK) rc = gather_combine_fetch(nullptr);
     if (rc != SMPC_OK) return rc;
   }
-  memcpy(u_inout, c->h_out, 3 * T * sizeof(float));
+  store_control_sequence(c, u_inout);
   if (out) {
     memset(out, 0, sizeof(*out));
     out->fail_flag = failed ? 1 : 0;
@@ -1786,7 +1831,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     if (need_f) flags[i] |= SD_LOCAL_FURTHEST;
     const bool ok = c->lane_now && c->cfg.iteration_count == 1 && !c->fail_in &&
       !(c->cfg.flags & (SMPC_FLAG_NO_SPECULATION | SMPC_FLAG_PROFILE)) && (!need_f || c->hint_valid) &&
-      c->poll_enabled;
+      c->poll_enabled && c->acker_r < 0.f;
     if (!ok) batched = false;
     if (i == 0) {
       window_bytes = c->lane_window_bytes;
@@ -1851,7 +1896,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
       if (rc != SMPC_OK) return rc;
       continue;
     }
-    memcpy(u_inout[i], c->h_out, 3 * T * sizeof(float));
+    store_control_sequence(c, u_inout[i]);
     if (outs) {
       smpc_tick_out* o = &outs[i];
       memset(o, 0, sizeof(*o));

@@ -98,6 +98,7 @@ struct SmpcDev {
   // the other registered critics (MODE 2)
   float con_weight, con_max_vel, con_min_vel;   // constraint_critic.cpp:36-38
   uint32_t con_power;
+  float con_acker_r;   // Ackermann min_turning_r (constraint_critic.cpp:54-59), < 0: other models
   const float* lut_cost;                         // [256] CostCritic repulsive term per 8-bit cost
   float cost_w254, cost_collision_cost;          // cost_weight / 254 (cost_critic.cpp:34)
   uint32_t cost_power;

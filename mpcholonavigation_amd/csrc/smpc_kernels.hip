@@ -659,7 +659,10 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
     float lin = 0.f;    // MODE 0: per-lane sum of every additive per-step term
     float uni = 0.f;    // MODE 0: wave-uniform terms
 
-    // ---- ConstraintCritic (constraint_critic.cpp:41-75), holonomic branch; MODE 2 only ----
+    // ---- ConstraintCritic (constraint_critic.cpp:41-75); MODE 2 only.  With the Ackermann
+    //      model (con_acker_r >= 0) each step also pays min_turning_r - |vx|/|wz| (:54-69;
+    //      float quotient, xt::maximum = select(a > b, a, b), so the 0/0 of a robot at rest
+    //      adds nothing) ----
     if (RARE && (p.flags & SD_CONSTRAINT)) {
       double sa = 0.0;
 #pragma unroll
@@ -670,7 +673,12 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
           const double vel_total = sgn * (double)sqrtf(vx[r] * vx[r] + vy[r] * vy[r]);
           const double out_max = fmax(vel_total - (double)p.con_max_vel, 0.0);
           const double out_min = fmax((double)p.con_min_vel - vel_total, 0.0);
-          sa += (out_max + out_min) * (double)p.dt;
+          if (p.con_acker_r >= 0.f) {
+            const double q = (double)(p.con_acker_r - fabsf(vx[r]) / fabsf(wz[r]));
+            sa += (out_max + out_min + (q > 0.0 ? q : 0.0)) * (double)p.dt;
+          } else {
+            sa += (out_max + out_min) * (double)p.dt;
+          }
         }
       }
       cost = add_cost_pow(cost, wave_sum_d(sa) * (double)p.con_weight, p.con_power);
@@ -1199,6 +1207,35 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
 }
 
 // ---------------------------------------------------------------------------
+// AckermannMotionModel::applyConstraints (motion_models.hpp:110-117), the last step of
+// applyControlSequenceConstraints (optimizer.cpp:248): where |vx|/|wz| < min_turning_r,
+// wz = sign(wz) |vx| / min_turning_r.  It needs the finished vx AND wz of a step, which the
+// column-parallel finishing kernels hold in different blocks, so it is its own T-thread
+// launch behind them and publishes the tick's completion word in their place.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) smpc_ackermann_constrain(float* __restrict__ u_dev,
+                                                               float* __restrict__ u_host,
+                                                               uint32_t T, float min_r, uint32_t seq)
+{
+  for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+    const float v = u_dev[t], w = u_dev[2 * T + t];
+    if (fabsf(v) / fabsf(w) < min_r) {
+      const float sgn = w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f);
+      const float nw = sgn * fabsf(v) / min_r;
+      u_dev[2 * T + t] = nw;
+      if (u_host) u_host[2 * T + t] = nw;
+    }
+  }
+  if (u_host && seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(u_host + 3 * T + 7), seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Device RNG: Philox4x32-10 + Box–Muller, one block of two samples per thread
 // (stands in for xt::random::randn, noise_generator.cpp:107-122).
 // ---------------------------------------------------------------------------
@@ -1376,6 +1413,14 @@ hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, floa
 {
   hipLaunchKernelGGL(smpc_combine_tuples, dim3(1), dim3(256), 0, st, tuples, G, T, neg_inv_temp,
                      vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used, host_out, seq);
+  return hipGetLastError();
+}
+
+hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float min_r, uint32_t seq,
+                                 hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_ackermann_constrain, dim3(1), dim3(256), 0, st, u_dev, u_host, T, min_r,
+                     seq);
   return hipGetLastError();
 }
 

@@ -31,14 +31,19 @@ void Optimizer::shutdown()
 
 void Optimizer::setMotionModel(const std::string & model)
 {
-  // The reference offers DiffDrive, Omni and Ackermann (optimizer.cpp:412-426); this
-  // build's fused path is the holonomic one the north star names.
+  // DiffDrive, Omni and Ackermann (optimizer.cpp:412-426).  Omni is the model the north star
+  // names; the two non-holonomic ones run the same kernels with vy held at zero (smpc.h).
   if (model == "Omni") {
+    motion_model_ = SMPC_MODEL_OMNI;
     return;
   }
-  if (model == "DiffDrive" || model == "Ackermann") {
-    throw std::runtime_error(
-            "Model " + model + " is not on the MI355X path: only Omni (holonomic) is built");
+  if (model == "DiffDrive") {
+    motion_model_ = SMPC_MODEL_DIFF_DRIVE;
+    return;
+  }
+  if (model == "Ackermann") {
+    motion_model_ = SMPC_MODEL_ACKERMANN;
+    return;
   }
   throw std::runtime_error(
           std::string(
@@ -115,6 +120,8 @@ void Optimizer::initialize(
   cfg.batch_size = settings_.batch_size;
   cfg.time_steps = settings_.time_steps;
   cfg.iteration_count = settings_.iteration_count;
+  cfg.motion_model = motion_model_;
+  cfg.ackermann_min_turning_r = ackermann_min_turning_r_;
   cfg.model_dt = settings_.model_dt;
   cfg.temperature = settings_.temperature;
   cfg.gamma = settings_.gamma;
@@ -271,7 +278,9 @@ void Optimizer::shiftControlSequence()
     };
   roll(control_sequence_.vx);
   roll(control_sequence_.wz);
-  roll(control_sequence_.vy);   // isHolonomic()
+  if (isHolonomic()) {
+    roll(control_sequence_.vy);
+  }
 }
 
 Twist2D Optimizer::getControlFromSequenceAsTwist()
@@ -280,7 +289,8 @@ Twist2D Optimizer::getControlFromSequenceAsTwist()
   Twist2D t;
   t.vx = control_sequence_.vx.at(offset);
   t.wz = control_sequence_.wz.at(offset);
-  t.vy = control_sequence_.vy.at(offset);
+  // toTwistStamped(vx, wz, ...) leaves linear.y at 0 for a non-holonomic model (:404-409)
+  t.vy = isHolonomic() ? control_sequence_.vy.at(offset) : 0.0f;
   return t;
 }
 
@@ -320,8 +330,10 @@ std::vector<std::array<float, 3>> Optimizer::getOptimizedTrajectory()
     const float s = t == 0 ? sinf(initial_yaw) : sinf(yaws[t - 1]);
     float dx = control_sequence_.vx[t] * c;
     float dy = control_sequence_.vx[t] * s;
-    dx = dx - control_sequence_.vy[t] * s;
-    dy = dy + control_sequence_.vy[t] * c;
+    if (isHolonomic()) {
+      dx = dx - control_sequence_.vy[t] * s;
+      dy = dy + control_sequence_.vy[t] * c;
+    }
     ax = t == 0 ? dx * dt : ax + dx * dt;
     ay = t == 0 ? dy * dt : ay + dy * dt;
     traj[t] = {static_cast<float>(pose_.x + static_cast<double>(ax)),

@@ -161,6 +161,9 @@ public:
   const models::OptimizerSettings & settings() const {return settings_;}
   const smpc_tick_out & lastTick() const {return last_out_;}
   void setVisualize(bool v) {visualize_ = v;}
+  bool isHolonomic() const {return motion_model_ == SMPC_MODEL_OMNI;}   // ref :235
+  // AckermannConstraints.min_turning_r (motion_models.hpp:91-95); call before initialize()
+  void setAckermannMinTurningRadius(float r) {ackermann_min_turning_r_ = r;}
 
 protected:
   void optimize();                         // ref :157-164 -> smpc_optimize
@@ -177,6 +180,8 @@ protected:
   std::array<models::Control, 4> control_history_{};
   CriticsConfig critics_{};
   bool regenerate_noises_{false};
+  uint32_t motion_model_{SMPC_MODEL_OMNI};
+  float ackermann_min_turning_r_{0.2f};
   bool visualize_{false};
   uint64_t noise_seed_{0};
   bool supplied_noise_{false};

@@ -71,6 +71,7 @@ int sortham_optimizer_create(
       cc.cost_scaling_factor = cfg->cost_scaling_factor;
       cc.inflation_radius = cfg->inflation_radius;
       o->opt.setVisualize(cfg->visualize != 0);
+      o->opt.setAckermannMinTurningRadius(b.ackermann_min_turning_r);
       o->opt.initialize(
         s, cfg->motion_model ? cfg->motion_model : "DiffDrive", cfg->controller_frequency, cc,
         cfg->regenerate_noises != 0, cfg->noise_seed, b.device);

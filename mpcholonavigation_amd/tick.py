@@ -71,6 +71,7 @@ def default_config(**kw) -> A.SmpcConfig:
     c.vx_max, c.vx_min, c.vy_max, c.wz_max = 0.5, -0.35, 0.5, 1.9
     c.vx_std, c.vy_std, c.wz_std = 0.2, 0.2, 0.4
     c.device, c.flags = -1, 0
+    c.ackermann_min_turning_r = 0.2   # include/.../motion_models.hpp:94
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)

@@ -69,6 +69,13 @@ void Optimizer::reset()
   cc.cost_scaling_factor = reg.cost_scaling_factor;
   cc.inflation_radius = reg.inflation_radius;
   host_.setVisualize(visualize_);
+  if (motion_model_name_ == "Ackermann") {
+    // AckermannMotionModel's constructor (include/.../motion_models.hpp:91-95)
+    auto getAcker = parameters_handler_->getParamGetter(name_ + ".AckermannConstraints");
+    float min_turning_r = 0.2f;
+    getAcker(min_turning_r, "min_turning_r", 0.2);
+    host_.setAckermannMinTurningRadius(min_turning_r);
+  }
   host_.initialize(settings_, motion_model_name_, controller_frequency_, cc, regenerate_noises_);
   generated_trajectories_.reset(settings_.batch_size, settings_.time_steps);
   RCLCPP_INFO(logger_, "Optimizer reset");

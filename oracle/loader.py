@@ -62,6 +62,7 @@ _PROTOTYPES = {
     "smpc_oracle_find_closest_path_pt": (C.c_uint32, [_f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "smpc_oracle_apply_constraints": (None, [_f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                              C.c_float]),
+    "smpc_oracle_motion_model_apply_constraints": (None, [_f32p, C.c_uint32, C.c_uint32, C.c_float]),
     "smpc_oracle_shift_control_sequence": (None, [_f32p, C.c_uint32]),
     "smpc_oracle_savitsky_golay": (None, [_f32p, C.c_uint32, _f32p, C.c_int]),
     "smpc_oracle_speed_limit": (None, [_f32p, C.c_double, C.c_int, _f32p]),

@@ -312,14 +312,38 @@ inline void savitsky_golay(float * u, uint32_t T, float * hist /*4x3*/, bool shi
   hist[3 * 3 + 2] = wz[offset];
 }
 
+// xt::maximum(a, b) is select(a > b, a, b) (xtensor xmath.hpp, math::maximum; third-party,
+// absent from the reference tree): a NaN first operand yields b.  Only the Ackermann
+// turning-radius term can see a NaN (0/0 for a robot at rest, state.vx[:,0] = wz[:,0] = 0).
+inline double xt_maximum(double a, double b) {return a > b ? a : b;}
+
 inline float clipf(float v, float lo, float hi) {return v < lo ? lo : (v > hi ? hi : v);}
 
-// src/optimizer.cpp:237-249 applyControlSequenceConstraints (Omni)
-inline void apply_constraints(float * u, uint32_t T, float vx_max, float vx_min, float vy,
-                              float wz)
+// MotionModel::applyConstraints: a no-op (include/.../motion_models.hpp:79) except for
+// Ackermann (:110-117): where |vx|/|wz| < min_turning_r, wz = sign(wz) * |vx| / min_turning_r.
+// xt::sign(0) is 0; |vx|/0 is +inf (or NaN for 0/0), never below the radius, so wz == 0 stays.
+inline void motion_model_apply_constraints(float * u, uint32_t T, float ackermann_min_r)
 {
+  if (!(ackermann_min_r >= 0.0f)) {
+    return;
+  }
   for (uint32_t t = 0; t < T; ++t) {
-    u[T + t] = clipf(u[T + t], -vy, vy);
+    const float v = u[t], w = u[2 * T + t];
+    if (fabsf(v) / fabsf(w) < ackermann_min_r) {
+      const float sgn = w > 0.0f ? 1.0f : (w < 0.0f ? -1.0f : 0.0f);
+      u[2 * T + t] = sgn * fabsf(v) / ackermann_min_r;
+    }
+  }
+}
+
+// src/optimizer.cpp:237-249 applyControlSequenceConstraints
+inline void apply_constraints(float * u, uint32_t T, float vx_max, float vx_min, float vy,
+                              float wz, bool holonomic = true, float ackermann_min_r = -1.0f)
+{
+  if (holonomic) {
+    for (uint32_t t = 0; t < T; ++t) {
+      u[T + t] = clipf(u[T + t], -vy, vy);
+    }
   }
   for (uint32_t t = 0; t < T; ++t) {
     u[t] = clipf(u[t], vx_min, vx_max);
@@ -327,6 +351,7 @@ inline void apply_constraints(float * u, uint32_t T, float vx_max, float vx_min,
   for (uint32_t t = 0; t < T; ++t) {
     u[2 * T + t] = clipf(u[2 * T + t], -wz, wz);
   }
+  motion_model_apply_constraints(u, T, ackermann_min_r);  // :248
 }
 
 }  // namespace
@@ -361,6 +386,12 @@ struct smpc_oracle {
 
   size_t B() const {return cfg.batch_size;}
   size_t T() const {return cfg.time_steps;}
+  // Optimizer::isHolonomic (src/optimizer.cpp:235)
+  bool holonomic() const {return cfg.motion_model == SMPC_MODEL_OMNI;}
+  float ackermann_r() const
+  {
+    return cfg.motion_model == SMPC_MODEL_ACKERMANN ? cfg.ackermann_min_turning_r : -1.0f;
+  }
 };
 
 namespace {
@@ -384,9 +415,11 @@ void draw_noise(smpc_oracle * o)
   for (size_t i = 0; i < B * T; ++i) {
     o->nwz[i] = normal_sample(o->seed, 1, o->epoch, base + i) * o->cfg.wz_std;
   }
-  for (size_t i = 0; i < B * T; ++i) {
-    o->nvy[i] = normal_sample(o->seed, 2, o->epoch, base + i) * o->cfg.vy_std;
-  }
+  if (o->holonomic()) {
+    for (size_t i = 0; i < B * T; ++i) {
+      o->nvy[i] = normal_sample(o->seed, 2, o->epoch, base + i) * o->cfg.vy_std;
+    }
+  }  // else noises_vy_ keeps the zeros of reset() (src/noise_generator.cpp:76-91,117)
   o->have_noise = true;
 }
 
@@ -419,7 +452,8 @@ void set_noised_controls(smpc_oracle * o, const float * u)
 }
 
 // Optimizer::updateStateVelocities (src/optimizer.cpp:251-273) +
-// MotionModel::predict (include/.../motion_models.hpp:53-66), Omni
+// MotionModel::predict (include/.../motion_models.hpp:53-66); a non-holonomic model never
+// writes state.vy, which keeps the zeros of State::reset
 void update_state_velocities(smpc_oracle * o, const smpc_tick_in * in)
 {
   const size_t B = o->B(), T = o->T();
@@ -432,8 +466,10 @@ void update_state_velocities(smpc_oracle * o, const smpc_tick_in * in)
   for (size_t b = 0; b < B; ++b) {
     o->wz[b * T] = swz;
   }
-  for (size_t b = 0; b < B; ++b) {
-    o->vy[b * T] = svy;
+  if (o->holonomic()) {
+    for (size_t b = 0; b < B; ++b) {
+      o->vy[b * T] = svy;
+    }
   }
   for (size_t b = 0; b < B; ++b) {
     for (size_t t = 1; t < T; ++t) {
@@ -445,15 +481,17 @@ void update_state_velocities(smpc_oracle * o, const smpc_tick_in * in)
       o->wz[b * T + t] = o->cwz[b * T + t - 1];
     }
   }
-  for (size_t b = 0; b < B; ++b) {
-    for (size_t t = 1; t < T; ++t) {
-      o->vy[b * T + t] = o->cvy[b * T + t - 1];
+  if (o->holonomic()) {
+    for (size_t b = 0; b < B; ++b) {
+      for (size_t t = 1; t < T; ++t) {
+        o->vy[b * T + t] = o->cvy[b * T + t - 1];
+      }
     }
   }
 }
 
 // Optimizer::integrateStateVelocities(Trajectories&, const State&)
-// (src/optimizer.cpp:313-343), holonomic branch taken
+// (src/optimizer.cpp:313-343)
 void integrate_state_velocities(smpc_oracle * o, const smpc_tick_in * in)
 {
   const size_t B = o->B(), T = o->T();
@@ -493,11 +531,13 @@ void integrate_state_velocities(smpc_oracle * o, const smpc_tick_in * in)
   for (size_t i = 0; i < B * T; ++i) {
     dy[i] = o->vx[i] * yaw_sin[i];
   }
-  for (size_t i = 0; i < B * T; ++i) {
-    dx[i] = dx[i] - o->vy[i] * yaw_sin[i];
-  }
-  for (size_t i = 0; i < B * T; ++i) {
-    dy[i] = dy[i] + o->vy[i] * yaw_cos[i];
+  if (o->holonomic()) {
+    for (size_t i = 0; i < B * T; ++i) {
+      dx[i] = dx[i] - o->vy[i] * yaw_sin[i];
+    }
+    for (size_t i = 0; i < B * T; ++i) {
+      dy[i] = dy[i] + o->vy[i] * yaw_cos[i];
+    }
   }
   // :339-342 x = position.x (double) + cumsum(dx * dt, 1), stored as float
   for (size_t b = 0; b < B; ++b) {
@@ -1045,6 +1085,7 @@ void score_constraint(smpc_oracle * o, const Tick &)
   const float max_vel = sqrtf(p.vx_max * p.vx_max + p.vy_max * p.vy_max);
   const float min_vel = min_sgn * sqrtf(p.vx_min * p.vx_min + p.vy_max * p.vy_max);
   const float dt = o->cfg.model_dt;
+  const float acker_r = o->ackermann_r();
   for (size_t i = 0; i < B; ++i) {
     double s = 0.0;
     for (size_t t = 0; t < T; ++t) {
@@ -1053,6 +1094,14 @@ void score_constraint(smpc_oracle * o, const Tick &)
       const double vel_total = sgn * static_cast<double>(std::sqrt(vx * vx + vy * vy));
       const double out_max = std::max(vel_total - static_cast<double>(max_vel), 0.0);
       const double out_min = std::max(static_cast<double>(min_vel) - vel_total, 0.0);
+      if (acker_r >= 0.0f) {
+        // :54-59 xt::maximum(min_turning_r - fabs(vx) / fabs(wz), 0.0): float quotient,
+        // double maximum; |vx|/0 = +inf gives 0, 0/0 = NaN propagates like xt's maximum
+        const float q = acker_r - std::fabs(vx) / std::fabs(o->wz[i * T + t]);
+        const double out_rad = xt_maximum(static_cast<double>(q), 0.0);
+        s += (out_max + out_min + out_rad) * static_cast<double>(dt);
+        continue;
+      }
       s += (out_max + out_min) * static_cast<double>(dt);
     }
     add_cost_pow(o->costs[i], s * static_cast<double>(p.cost_weight), p.cost_power);
@@ -1177,6 +1226,11 @@ void score_velocity_deadband(smpc_oracle * o, const Tick &)
   for (size_t i = 0; i < B; ++i) {
     double s = 0.0;
     for (size_t t = 0; t < T; ++t) {
+      if (!o->holonomic()) {  // :78-97, no vy term
+        s += (std::max(d0 - static_cast<double>(std::fabs(o->vx[i * T + t])), 0.0) +
+          std::max(d2 - static_cast<double>(std::fabs(o->wz[i * T + t])), 0.0)) * dt;
+        continue;
+      }
       s += (std::max(d0 - static_cast<double>(std::fabs(o->vx[i * T + t])), 0.0) +
         std::max(d1 - static_cast<double>(std::fabs(o->vy[i * T + t])), 0.0) +
         std::max(d2 - static_cast<double>(std::fabs(o->wz[i * T + t])), 0.0)) * dt;
@@ -1239,6 +1293,9 @@ void add_gamma_terms(smpc_oracle * o, const float * u)
     }
     o->costs[b] += gwz * s;
   }
+  if (!o->holonomic()) {
+    return;
+  }
   for (size_t b = 0; b < B; ++b) {
     float s = 0.0f;
     for (size_t t = 0; t < T; ++t) {
@@ -1280,7 +1337,9 @@ void update_control_sequence(smpc_oracle * o, float * u)
     }
     for (size_t t = 0; t < T; ++t) {
       uvx[t] = static_cast<float>(ax[t]);
-      uvy[t] = static_cast<float>(ay[t]);
+      if (o->holonomic()) {
+        uvy[t] = static_cast<float>(ay[t]);
+      }
       uwz[t] = static_cast<float>(az[t]);
     }
     o->last_sumw = static_cast<float>(sum);
@@ -1310,13 +1369,16 @@ void update_control_sequence(smpc_oracle * o, float * u)
     }
     for (size_t t = 0; t < T; ++t) {
       uvx[t] = ax[t];
-      uvy[t] = ay[t];
+      if (o->holonomic()) {
+        uvy[t] = ay[t];
+      }
       uwz[t] = az[t];
     }
     o->last_sumw = sum;
   }
   o->last_min = cmin;
-  apply_constraints(u, static_cast<uint32_t>(T), o->c_vx_max, o->c_vx_min, o->c_vy, o->c_wz);
+  apply_constraints(u, static_cast<uint32_t>(T), o->c_vx_max, o->c_vx_min, o->c_vy, o->c_wz,
+                    o->holonomic(), o->ackermann_r());
 }
 
 int check_ready(smpc_oracle * o, const smpc_tick_in * in)
@@ -1372,8 +1434,11 @@ int smpc_oracle_create(const smpc_config * cfg, smpc_oracle ** out)
   if (!cfg || !out || cfg->batch_size == 0 || cfg->time_steps == 0) {
     return SMPC_ERR_INVALID;
   }
-  if (cfg->motion_model != SMPC_MODEL_OMNI) {
+  if (cfg->motion_model > SMPC_MODEL_ACKERMANN) {
     return SMPC_ERR_UNSUPPORTED;
+  }
+  if (cfg->motion_model == SMPC_MODEL_ACKERMANN && !(cfg->ackermann_min_turning_r >= 0.0f)) {
+    return SMPC_ERR_INVALID;
   }
   smpc_oracle * o = new (std::nothrow) smpc_oracle();
   if (!o) {
@@ -1670,7 +1735,8 @@ int smpc_oracle_shard_combine(smpc_oracle * o, const float * tuples, uint32_t n_
   for (size_t i = 0; i < 3 * T; ++i) {
     u_out[i] = static_cast<float>(acc[i] / sum);
   }
-  apply_constraints(u_out, static_cast<uint32_t>(T), o->c_vx_max, o->c_vx_min, o->c_vy, o->c_wz);
+  apply_constraints(u_out, static_cast<uint32_t>(T), o->c_vx_max, o->c_vx_min, o->c_vy, o->c_wz,
+                    o->holonomic(), o->ackermann_r());
   if (out) {
     memset(out, 0, sizeof(*out));
     out->fail_flag = (non_colliding == 0.0 && o->critics.obstacles.enabled) ? 1 : 0;
@@ -1839,6 +1905,13 @@ void smpc_oracle_apply_constraints(float * u, uint32_t T, float vx_max, float vx
   apply_constraints(u, T, vx_max, vx_min, vy_max, wz_max);
 }
 
+void smpc_oracle_motion_model_apply_constraints(float * u, uint32_t T, uint32_t motion_model,
+                                                float ackermann_min_turning_r)
+{
+  motion_model_apply_constraints(
+    u, T, motion_model == SMPC_MODEL_ACKERMANN ? ackermann_min_turning_r : -1.0f);
+}
+
 // Optimizer::shiftControlSequence (src/optimizer.cpp:206-225), holonomic
 void smpc_oracle_shift_control_sequence(float * u, uint32_t T)
 {
@@ -1911,6 +1984,7 @@ void smpc_config_default(smpc_config * c)
   c->vy_std = 0.2f;
   c->wz_std = 0.4f;
   c->device = -1;
+  c->ackermann_min_turning_r = 0.2f;  // motion_models.hpp:94
 }
 
 void smpc_critic_params_default(smpc_critic_params * p)

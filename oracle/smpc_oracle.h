@@ -117,6 +117,9 @@ uint32_t smpc_oracle_find_closest_path_pt(const float* vec, uint32_t n, float di
 /* host-side control-sequence helpers (u = {vx[T], vy[T], wz[T]}) */
 void smpc_oracle_apply_constraints(float* u, uint32_t T, float vx_max, float vx_min,
                                    float vy_max, float wz_max);
+/* MotionModel::applyConstraints [ref include/.../motion_models.hpp:79,110-117] */
+void smpc_oracle_motion_model_apply_constraints(float* u, uint32_t T, uint32_t motion_model,
+                                                float ackermann_min_turning_r);
 void smpc_oracle_shift_control_sequence(float* u, uint32_t T);
 /* history: 4 x {vx, vy, wz}, oldest first [ref optimizer.hpp control_history_] */
 void smpc_oracle_savitsky_golay(float* u, uint32_t T, float* history, int shift);

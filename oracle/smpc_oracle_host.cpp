@@ -128,10 +128,16 @@ int smpc_oracle_opt_eval_control(
   // getControlFromSequenceAsTwist (:396-410)
   const uint32_t offset = o->shift_control_sequence ? 1 : 0;
   twist[0] = o->u[offset];
-  twist[1] = o->u[T + offset];
+  const bool holonomic = o->cfg.motion_model == SMPC_MODEL_OMNI;   // isHolonomic() (:235)
+  twist[1] = holonomic ? o->u[T + offset] : 0.0;   // toTwistStamped(vx, wz, ...) (:409)
   twist[2] = o->u[2 * T + offset];
   if (o->shift_control_sequence) {
+    // shiftControlSequence (:206-225) rolls vy only if holonomic
+    std::vector<float> vy_row(o->u.begin() + T, o->u.begin() + 2 * T);
     smpc_oracle_shift_control_sequence(o->u.data(), T);
+    if (!holonomic) {
+      std::copy(vy_row.begin(), vy_row.end(), o->u.begin() + T);
+    }
   }
   if (out) {*out = o->last;}
   return SMPC_OK;
@@ -198,8 +204,10 @@ int smpc_oracle_opt_get_optimized_trajectory(smpc_oracle_opt * o, float * xyyaw)
   for (uint32_t t = 0; t < T; ++t) {
     dx[t] = vx[t] * yaw_cos[t];
     dy[t] = vx[t] * yaw_sin[t];
-    dx[t] = dx[t] - vy[t] * yaw_sin[t];
-    dy[t] = dy[t] + vy[t] * yaw_cos[t];
+    if (o->cfg.motion_model == SMPC_MODEL_OMNI) {   // :304-307
+      dx[t] = dx[t] - vy[t] * yaw_sin[t];
+      dy[t] = dy[t] + vy[t] * yaw_cos[t];
+    }
   }
   float ax = 0.0f, ay = 0.0f;
   for (uint32_t t = 0; t < T; ++t) {

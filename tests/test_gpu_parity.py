@@ -485,3 +485,76 @@ def test_consider_footprint_needs_a_footprint(Smpc):
     g.set_footprint(FOOTPRINT, 0.31, 10.0)
     with pytest.raises(Exception, match="both ObstaclesCritic and CostCritic"):
         g.optimize(scn.tick, scn.u0)
+
+
+FIVE = ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward")
+
+
+@pytest.mark.parametrize("model,names,B,T,iters", [
+    (A.SMPC_MODEL_DIFF_DRIVE, FIVE, 2000, 56, 1),
+    (A.SMPC_MODEL_DIFF_DRIVE, ALL11, 1500, 40, 2),
+    (A.SMPC_MODEL_DIFF_DRIVE, FIVE, 300, 128, 1),
+    (A.SMPC_MODEL_ACKERMANN, FIVE, 2000, 56, 1),
+    (A.SMPC_MODEL_ACKERMANN, ALL11, 3000, 64, 2),
+    (A.SMPC_MODEL_ACKERMANN, ("constraint", "velocity_deadband", "path_follow"), 1000, 30, 3),
+    (A.SMPC_MODEL_DIFF_DRIVE, FIVE, 131072, 64, 1),      # lane-per-rollout pass
+    (A.SMPC_MODEL_ACKERMANN, FIVE, 131072, 64, 1)])
+def test_non_holonomic_motion_models_parity(Smpc, Oracle, model, names, B, T, iters):
+    """DiffDrive and Ackermann (motion_models.hpp:85-171 and the
+    isHolonomic() branches of optimizer.cpp): no vy noise, state.vy = 0, no vy in the
+    integration, gamma term, update or Twist; the caller's control_sequence.vy row is neither
+    read nor written; Ackermann bounds the turning radius of the result and ConstraintCritic
+    gains its term.  The library runs these as the Omni kernels with vy held at zero; the oracle
+    restates the reference's branches literally (pinned by motion_model_tests.cpp KATs)."""
+    cfg, scn, noise = make_case(B, T)
+    cfg.motion_model = model
+    cfg.iteration_count = iters
+    cfg.ackermann_min_turning_r = 0.5
+    cr = _extra_critics(names, 1)
+    tick = scn.tick
+    tick.speed = (tick.speed[0], 0.3, tick.speed[2])   # sideways speed: ignored by these models
+    tick.goal_checker_xy_tolerance = 0.25
+    u0 = scn.u0.copy()
+    u0[1] = 0.123                         # a stale vy row: not read, and returned as it was
+    if model == A.SMPC_MODEL_ACKERMANN:
+        # a tight turn in the first half of the horizon: the weighted update lands near it,
+        # inside the minimum turning radius, so applyConstraints has work to do
+        u0[0, :T // 2] = 0.25
+        u0[2, :T // 2] = np.where(np.arange(T // 2) % 8 < 4, 0.9, -0.9)
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise, critics=cr, tick=tick, u0=u0)
+    assert np.array_equal(ug[1], u0[1]) and np.array_equal(uo[1], u0[1])
+    nvx, nvy, nwz = g.get_noise()
+    assert not nvy.any()                  # noises_vy_ stays zero (noise_generator.cpp:117)
+    assert og.non_colliding == oo.non_colliding
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
+                  label=f"motion model {model} {names} {B}x{T} x{iters}")
+    if B >= 131072:
+        assert og.pass_kind == 1
+    if model == A.SMPC_MODEL_ACKERMANN:
+        # the turning-radius bound held, and it was active somewhere
+        ratio = np.abs(ug[0]) / np.maximum(np.abs(ug[2]), 1e-30)
+        assert np.all(ratio >= 0.5 * (1 - 1e-6))
+        cfg2, _, _ = make_case(B, T)
+        cfg2.motion_model, cfg2.iteration_count = A.SMPC_MODEL_DIFF_DRIVE, iters
+        o2 = Oracle(cfg2)
+        configure(o2, scn, critics=cr, noise=noise)
+        ud, _ = o2.optimize(tick, u0)
+        assert not np.array_equal(ud[2], uo[2])
+
+
+def test_non_holonomic_model_draws_no_vy_noise(Smpc, Oracle):
+    """Device RNG with a DiffDrive model: vx and wz streams as for Omni, vy all zero, and the
+    tick matches the oracle drawing from the same Philox streams."""
+    cfg, scn, _ = make_case(4096, 56)
+    cfg.motion_model = A.SMPC_MODEL_DIFF_DRIVE
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn)
+        obj.seed(77)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    gx, gy, gz = g.get_noise()
+    ox, oy, oz = o.get_noise()
+    assert not gy.any() and not oy.any()
+    assert np.max(np.abs(gx - ox)) < 2e-6 and np.max(np.abs(gz - oz)) < 2e-6
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label="diffdrive rng")

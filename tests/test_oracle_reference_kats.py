@@ -244,6 +244,86 @@ def test_constraints_critic_kat():
     assert costs.sum() > 0 and abs(costs[1] - 1.2) < 0.01
 
 
+def test_constraints_critic_ackermann_kat():
+    """critics_tests.cpp:100-116 (the Ackermann part): vx 0.40, wz 1.5 -> radius 0.267 >= 0.2,
+    no cost; wz 2.5 -> 4.0 weight * 0.1 model_dt * (0.2 - 0.4 / 2.5) * 30 steps = 0.48."""
+    B, T = 1000, 30
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1,
+                              motion_model=A.SMPC_MODEL_ACKERMANN))
+    o.set_critics(_critics_with("constraint", vx_max=0.5, vy_max=0.0, vx_min=-0.35))
+    costs = np.zeros(B, np.float32)
+    vx = np.full((B, T), 0.40, np.float32)
+    vy = np.zeros((B, T), np.float32)
+    wz = np.full((B, T), 1.5, np.float32)
+    o.lib.smpc_oracle_set_state_velocities(o.h, ptr(vx), ptr(vy), ptr(wz))
+    _score(o, "constraint", _tick(), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    wz[:] = 2.5
+    o.lib.smpc_oracle_set_state_velocities(o.h, ptr(vx), ptr(vy), ptr(wz))
+    _score(o, "constraint", _tick(), costs)
+    assert costs.sum() > 0 and abs(costs[1] - 0.48) < 0.01
+    # a robot at rest: 0/0 is NaN, xt::maximum(NaN, 0) = 0, no cost and no NaN
+    costs[:] = 0
+    vx[:] = 0
+    wz[:] = 0
+    o.lib.smpc_oracle_set_state_velocities(o.h, ptr(vx), ptr(vy), ptr(wz))
+    _score(o, "constraint", _tick(), costs)
+    assert np.all(costs == 0)
+
+
+# --------------------------------------------------------------------------
+# test/motion_model_tests.cpp
+# --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("model,holonomic", [(A.SMPC_MODEL_DIFF_DRIVE, False), (A.SMPC_MODEL_OMNI, True),
+                                             (A.SMPC_MODEL_ACKERMANN, False)])
+def test_motion_model_predict_kat(model, holonomic):
+    """motion_model_tests.cpp:36-60 (DiffDriveTest), :81-107 (OmniTest), :128-153
+    (AckermannTest): predict copies the controls into vx, wz (and vy only if holonomic); a
+    non-holonomic state.vy stays zero."""
+    B, T = 1000, 50
+    o = Oracle(default_config(batch_size=B, time_steps=T, motion_model=model))
+    cvx = np.full((B, T), 10.0, np.float32)
+    cvy = np.full((B, T), 5.0, np.float32)
+    cwz = np.full((B, T), 1.0, np.float32)
+    tick = _tick(speed=(10.0, 5.0, 1.0))     # column 0 = the measured speed
+    assert o.lib.smpc_oracle_update_state_velocities(o.h, C.byref(tick.c), ptr(cvx), ptr(cvy),
+                                                     ptr(cwz)) == 0
+    vx, vy, wz = (np.empty((B, T), np.float32) for _ in range(3))
+    o.lib.smpc_oracle_get_state_velocities(o.h, ptr(vx), ptr(vy), ptr(wz))
+    assert np.array_equal(vx, cvx) and np.array_equal(wz, cwz)
+    assert np.array_equal(vy, cvy if holonomic else np.zeros_like(cvy))
+
+
+@pytest.mark.parametrize("model", [A.SMPC_MODEL_DIFF_DRIVE, A.SMPC_MODEL_OMNI])
+def test_motion_model_constraints_are_empty_kat(oracle_lib, model):
+    """motion_model_tests.cpp:62-72, :109-119: applyConstraints leaves vx, vy, wz alone."""
+    T = 50
+    u = np.tile((np.arange(T, dtype=np.float32) ** 3)[None], (3, 1)).copy()
+    before = u.copy()
+    oracle_lib.smpc_oracle_motion_model_apply_constraints(ptr(u), T, model, 0.2)
+    assert np.array_equal(u, before)
+
+
+@pytest.mark.parametrize("vx_sign,wz_sign", [(1, 1), (-1, 1), (-1, -1)])
+def test_ackermann_constraints_kat(oracle_lib, vx_sign, wz_sign):
+    """motion_model_tests.cpp:155-176 (AckermannTest) and :211-244 (AckermannReversingTest):
+    vx = +-i^3, wz = +-i^4: vx unchanged, wz reduced but of the same sign, and
+    |vx| / |wz| >= min_turning_r = 0.2 everywhere past i = 0."""
+    T = 50
+    i = np.arange(T, dtype=np.float32)
+    u = np.zeros((3, T), np.float32)
+    u[0] = vx_sign * i * i * i
+    u[2] = wz_sign * i * i * i * i
+    before = u.copy()
+    oracle_lib.smpc_oracle_motion_model_apply_constraints(ptr(u), T, A.SMPC_MODEL_ACKERMANN, 0.2)
+    assert np.array_equal(u[0], before[0]) and np.array_equal(u[1], before[1])
+    assert not np.array_equal(u[2], before[2])
+    assert np.all(u[2, 1:] * wz_sign > 0)
+    assert np.all(np.abs(u[0, 1:]) / np.abs(u[2, 1:]) >= 0.2 - 1e-7)
+    assert u[2, 0] == 0.0            # 0/0: not below the radius, untouched
+
+
 def test_goal_critic_kat():
     """critics_tests.cpp:172-222: far from the goal -> 0; pose 1.0, goal 0.5, trajectories 0 ->
     0.5 * 5.0 = 2.5 per rollout, 2500 in all."""
