@@ -304,6 +304,26 @@ def main():
             except Exception as e:     # RCCL not loadable: same protocol through torch.distributed
                 print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed",
                       file=sys.stderr, flush=True)
+        if so is not None:
+            # One tick through each implementation from the same state must give the same control
+            # sequence on every rank; otherwise (or if the native tick raises) every rank drops
+            # to the torch.distributed driver together.
+            agree = 0
+            try:
+                u_nat, o_nat = g.shard_tick(scn.tick, scn.u0, False)
+                u_ref, o_ref = ShardedOptimizer(HipShard(g), speculate=False).optimize(scn.tick, scn.u0)
+                agree = int(np.allclose(u_nat, u_ref, rtol=0, atol=1e-6) and
+                            o_nat.furthest_reached_path_point == o_ref.furthest_reached_path_point)
+            except Exception as e:
+                print(f"[bench] rank {rank}: native exchange self-check raised: {e}", file=sys.stderr,
+                      flush=True)
+            g.set_stream(-1)      # SMPC_STREAM_OWN: back to the ctx's own stream
+            t = torch.tensor([agree], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) != 1:
+                print("[bench] native RCCL exchange disagrees with the torch.distributed driver; "
+                      "using torch.distributed", file=sys.stderr, flush=True)
+                so = None
         if so is None:
             so = ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
             exchange_impl = "RCCL through torch.distributed (ShardedOptimizer)"
