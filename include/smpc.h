@@ -337,6 +337,23 @@ int smpc_set_costmap(smpc_ctx* ctx, const uint8_t* cells, uint32_t width,
                      double resolution, int track_unknown, float inscribed_radius,
                      float cost_scaling_factor, float inflation_radius);
 
+/* Costmap hand-off at the controller's rate.  The reference holds a
+ * Costmap2D* and reads it under the costmap mutex during the tick
+ * [ref src/controller.cpp:99-103]; a device needs its own copy.  smpc_set_costmap() may be
+ * called every tick: it keeps a pinned host mirror, uploads only the band of rows that
+ * changed since the previous call (nothing for an unchanged map of the same size; the
+ * lookup tables are rebuilt only when resolution / inflation parameters change) and
+ * returns without waiting for the DMA — the next tick is ordered behind it.
+ * A caller that knows the updated window (Costmap2D's updated bounds) can hand over just
+ * that: `cells` points at the window's first cell inside the caller's map, whose rows are
+ * `row_stride` bytes apart; geometry and parameters stay those of the last
+ * smpc_set_costmap(). */
+int smpc_update_costmap_region(smpc_ctx* ctx, const uint8_t* cells, uint32_t row_stride,
+                               uint32_t x0, uint32_t y0, uint32_t width, uint32_t height);
+/* Bytes uploaded by the last smpc_set_costmap / smpc_update_costmap_region call, and in
+ * total (either pointer may be NULL). */
+int smpc_costmap_upload_bytes(const smpc_ctx* ctx, uint64_t* last_call, uint64_t* total);
+
 /* Supplied-noise (parity) mode: the three [B,T] row-major noise tensors
  * NoiseGenerator holds [ref tools/noise_generator.hpp:97-99], already scaled
  * by the sampling std.  Host pointers; copied. */

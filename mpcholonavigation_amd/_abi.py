@@ -247,6 +247,9 @@ PROTOTYPES = {
     "smpc_set_costmap": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
                                    C.c_double, C.c_double, C.c_int, C.c_float, C.c_float,
                                    C.c_float]),
+    "smpc_update_costmap_region": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_uint32]),
+    "smpc_costmap_upload_bytes": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "smpc_set_footprint": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_double, C.c_double]),
     "smpc_set_noise": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smpc_seed": (C.c_int, [_ctx, C.c_uint64]),

@@ -109,7 +109,8 @@ constexpr uint32_t kLdsPerCu = 160 * 1024;
 inline uint32_t align_up(uint32_t v, uint32_t a) {return (v + a - 1) / a * a;}
 
 struct HostCostmap {
-  std::vector<uint8_t> cells;
+  uint8_t* cells = nullptr;   // pinned mirror of the device copy: the host-side lookups read it
+  size_t cap = 0;             // (path validity, first rollout point) and uploads DMA out of it
   uint32_t W = 0, H = 0;
   double ox = 0, oy = 0, res = 1;
   bool track_unknown = false;
@@ -183,6 +184,9 @@ struct smpc_ctx {
   HostCostmap map;
   uint8_t* d_map = nullptr;
   size_t d_map_bytes = 0;
+  hipEvent_t ev_map = nullptr;       // behind the last costmap upload
+  bool map_pending = false;          // that upload may still be reading the pinned mirror
+  uint64_t map_bytes_last = 0, map_bytes_total = 0;   // uploaded by the last call / so far
   // per-tick block
   SmpcLut* d_lut = nullptr;
   SmpcLut* h_lut = nullptr;     // pinned
@@ -252,6 +256,18 @@ int fail(smpc_ctx* c, int code, const std::string& msg)
                   std::string(#call) + ": " + hipGetErrorString(e__));                \
   } while (0)
 
+// A costmap upload is asynchronous (pinned mirror -> device on the ctx's stream).  Kernels of
+// the same stream are ordered behind it; this host-side wait covers the rest: a tick
+// launched on another stream (grouped ticks, smpc_set_stream) and the next overwrite of
+// the mirror.
+int wait_map_upload(smpc_ctx* c)
+{
+  if (!c->map_pending) return SMPC_OK;
+  HIPCK(c, hipEventSynchronize(c->ev_map));
+  c->map_pending = false;
+  return SMPC_OK;
+}
+
 void free_ctx(smpc_ctx* c)
 {
   if (!c) return;
@@ -260,6 +276,8 @@ void free_ctx(smpc_ctx* c)
          c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
     if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
+  if (c->map.cells) (void)hipHostFree(c->map.cells);
+  if (c->ev_map) (void)hipEventDestroy(c->ev_map);
   if (c->d_tick && !c->defer_upload) (void)hipFree(c->d_tick);
   if (c->d_lut) (void)hipFree(c->d_lut);
   if (c->d_lut_fp) (void)hipFree(c->d_lut_fp);
@@ -657,6 +675,10 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     }
   }
 
+  {
+    const int rc_map = wait_map_upload(c);
+    if (rc_map != SMPC_OK) return rc_map;
+  }
   if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev0, c->stream));
   if (!c->defer_upload)
     HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
@@ -1132,6 +1154,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   c->stream = c->own_stream;
   c->poll_enabled = getenv("SMPC_NO_POLL") == nullptr;
   CK(hipEventCreate(&c->ev0));
+  CK(hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev1));
   for (auto& e : c->evp) CK(hipEventCreate(&e));
   const uint32_t T = cfg->time_steps;
@@ -1255,24 +1278,99 @@ int smpc_set_costmap(smpc_ctx* c, const uint8_t* cells, uint32_t width, uint32_t
   if (!cells || width == 0 || height == 0 || !(resolution > 0.0))
     return fail(c, SMPC_ERR_INVALID, "bad costmap");
   HIPCK(c, hipSetDevice(c->device));
+  int rc = wait_map_upload(c);   // the previous upload reads the mirror this call overwrites
+  if (rc != SMPC_OK) return rc;
+  HostCostmap& m = c->map;
   const size_t bytes = static_cast<size_t>(width) * height;
+  bool same_size = m.set && m.W == width && m.H == height;
   if (bytes > c->d_map_bytes) {
+    // the stream may still read the old device copy (an un-waited tick): drain it first
+    HIPCK(c, hipStreamSynchronize(c->stream));
     if (c->d_map) HIPCK(c, hipFree(c->d_map));
     c->d_map = nullptr;
+    c->d_map_bytes = 0;
     HIPCK(c, hipMalloc(&c->d_map, (bytes + 255) / 256 * 256));
     c->d_map_bytes = bytes;
+    same_size = false;
   }
-  HostCostmap& m = c->map;
-  m.cells.assign(cells, cells + bytes);
+  if (bytes > m.cap) {
+    if (m.cells) HIPCK(c, hipHostFree(m.cells));
+    m.cells = nullptr;
+    m.cap = 0;
+    HIPCK(c, hipHostMalloc(reinterpret_cast<void**>(&m.cells), (bytes + 4095) / 4096 * 4096, hipHostMallocDefault));
+    m.cap = bytes;
+    same_size = false;
+  }
+  // The controller hands over the whole costmap every tick (controller.cpp:99-103) while the
+  // costmap itself changes at its own, lower update rate: only the band of rows that differ
+  // from the mirror is copied and uploaded (nothing at all for an unchanged map).
+  uint32_t y0 = height, y1 = 0;
+  if (same_size) {
+    for (uint32_t y = 0; y < height; ++y) {
+      const size_t o = static_cast<size_t>(y) * width;
+      if (memcmp(m.cells + o, cells + o, width) != 0) {
+        memcpy(m.cells + o, cells + o, width);
+        if (y < y0) y0 = y;
+        y1 = y;
+      }
+    }
+  } else {
+    memcpy(m.cells, cells, bytes);
+    y0 = 0;
+    y1 = height - 1;
+  }
+  // the lookup tables depend on these, not on the cells
+  const bool same_params = m.set && m.res == resolution && m.track_unknown == (track_unknown != 0) &&
+    m.inscribed_radius == inscribed_radius && m.cost_scaling_factor == cost_scaling_factor &&
+    m.inflation_radius == inflation_radius;
   m.W = width; m.H = height; m.ox = origin_x; m.oy = origin_y; m.res = resolution;
   m.track_unknown = track_unknown != 0;
   m.inscribed_radius = inscribed_radius;
   m.cost_scaling_factor = cost_scaling_factor;
   m.inflation_radius = inflation_radius;
   m.set = true;
-  c->map_version++;
-  HIPCK(c, hipMemcpyAsync(c->d_map, m.cells.data(), bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));
+  if (!same_params) c->map_version++;
+  c->map_bytes_last = 0;
+  if (y0 <= y1) {
+    const size_t o = static_cast<size_t>(y0) * width, n = static_cast<size_t>(y1 - y0 + 1) * width;
+    HIPCK(c, hipMemcpyAsync(c->d_map + o, m.cells + o, n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->ev_map, c->stream));
+    c->map_pending = true;
+    c->map_bytes_last = n;
+    c->map_bytes_total += n;
+  }
+  return SMPC_OK;
+}
+
+int smpc_update_costmap_region(smpc_ctx* c, const uint8_t* cells, uint32_t row_stride, uint32_t x0,
+                               uint32_t y0, uint32_t width, uint32_t height)
+{
+  if (!c || !cells) return SMPC_ERR_INVALID;
+  HostCostmap& m = c->map;
+  if (!m.set) return fail(c, SMPC_ERR_STATE, "smpc_set_costmap first");
+  if (width == 0 || height == 0 || row_stride < width || x0 >= m.W || y0 >= m.H || width > m.W - x0 ||
+      height > m.H - y0)
+    return fail(c, SMPC_ERR_INVALID, "region outside the costmap");
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = wait_map_upload(c);
+  if (rc != SMPC_OK) return rc;
+  for (uint32_t y = 0; y < height; ++y)
+    memcpy(m.cells + static_cast<size_t>(y0 + y) * m.W + x0, cells + static_cast<size_t>(y) * row_stride, width);
+  const size_t o = static_cast<size_t>(y0) * m.W + x0;
+  HIPCK(c, hipMemcpy2DAsync(c->d_map + o, m.W, m.cells + o, m.W, width, height, hipMemcpyHostToDevice,
+                            c->stream));
+  HIPCK(c, hipEventRecord(c->ev_map, c->stream));
+  c->map_pending = true;
+  c->map_bytes_last = static_cast<uint64_t>(width) * height;
+  c->map_bytes_total += c->map_bytes_last;
+  return SMPC_OK;
+}
+
+int smpc_costmap_upload_bytes(const smpc_ctx* c, uint64_t* last_call, uint64_t* total)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (last_call) *last_call = c->map_bytes_last;
+  if (total) *total = c->map_bytes_total;
   return SMPC_OK;
 }
 
@@ -1508,6 +1606,8 @@ int smpc_selftest_lane_reduce(smpc_ctx* c, const float* v, const float* w, float
 int smpc_set_stream(smpc_ctx* c, void* hip_stream)
 {
   if (!c) return SMPC_ERR_INVALID;
+  const int rc = wait_map_upload(c);   // it went out on the stream being left
+  if (rc != SMPC_OK) return rc;
   c->stream = hip_stream == SMPC_STREAM_OWN ? c->own_stream : static_cast<hipStream_t>(hip_stream);
   return SMPC_OK;
 }

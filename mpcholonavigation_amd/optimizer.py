@@ -104,6 +104,21 @@ class Smpc:
             self.h, _ptr(cells), w, h, origin_x, origin_y, resolution, int(track_unknown),
             inscribed_radius, cost_scaling_factor, inflation_radius))
 
+    def update_costmap_region(self, cells, x0, y0, width, height):
+        """Hand over the window [y0:y0+height, x0:x0+width] of the caller's full map `cells`."""
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        if cells.ndim != 2:
+            raise ValueError("cells must be the full [height, width] map")
+        first = cells[y0:, x0:]          # a view: the pointer of the window's first cell
+        self._ck(self.lib.smpc_update_costmap_region(
+            self.h, C.c_void_p(first.ctypes.data), cells.shape[1], x0, y0, width, height))
+
+    def costmap_upload_bytes(self):
+        """(bytes uploaded by the last set_costmap / update_costmap_region, total so far)."""
+        last, total = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.smpc_costmap_upload_bytes(self.h, C.byref(last), C.byref(total)))
+        return last.value, total.value
+
     def set_footprint(self, xy, circumscribed_radius, layer_cost_scaling_factor=10.0):
         """Robot footprint [n, 2] (robot frame) for consider_footprint=true."""
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)

@@ -297,3 +297,55 @@ def test_grouped_contexts_tick_in_one_launch():
     grp.close()
     for g in alone + grouped:
         g.close()
+
+
+@pytest.mark.parametrize("B,T,M", [(4096, 56, 200), (131072, 64, 200), (8192, 64, 2000)])
+def test_costmap_handoff_uploads_only_what_changed(B, T, M):
+    """the controller hands the costmap over every tick.  An unchanged
+    map uploads nothing, a changed band of rows uploads that band, an explicit window uploads
+    the window — and the tick that follows is bit-identical to one on a fresh context that
+    was given the final map whole (the device copy and the pinned host mirror both match)."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    g, scn = _ctx(B, T, M, seed=5)
+    full = M * M
+    assert g.costmap_upload_bytes() == (full, full)
+    g.optimize(scn.tick, scn.u0)
+    configure(g, scn)                                   # the same map again: nothing to do
+    assert g.costmap_upload_bytes() == (0, full)
+
+    # the inflation around the robot changes: a band of 9 rows differs
+    cells = scn.cells.copy()
+    rr = int((scn.tick.pose_y - scn.origin_y) / scn.resolution)
+    rc = int((scn.tick.pose_x - scn.origin_x) / scn.resolution)
+    cells[rr - 4:rr + 5, rc - 30:rc + 30] = np.maximum(cells[rr - 4:rr + 5, rc - 30:rc + 30], 100)
+    g.set_costmap(cells, scn.origin_x, scn.origin_y, scn.resolution, inscribed_radius=scn.inscribed_radius,
+                  cost_scaling_factor=scn.cost_scaling_factor, inflation_radius=scn.inflation_radius)
+    assert g.costmap_upload_bytes()[0] == 9 * M         # rows rr-4 .. rr+4
+    g.optimize(scn.tick, scn.u0)
+    c1 = g.get_costs()
+
+    # then a window (where every rollout starts) is handed over explicitly
+    cells[rr - 2:rr + 2, rc - 3:rc + 3] = 150
+    g.update_costmap_region(cells, rc - 3, rr - 2, 6, 4)
+    assert g.costmap_upload_bytes()[0] == 24
+    u2, o2 = g.optimize(scn.tick, scn.u0)
+    c2 = g.get_costs()
+    assert not np.array_equal(c1, c2)                   # the window mattered
+
+    f = Smpc(default_config(batch_size=B, time_steps=T))
+    f.set_critics(default_critics())
+    f.set_costmap(cells, scn.origin_x, scn.origin_y, scn.resolution, inscribed_radius=scn.inscribed_radius,
+                  cost_scaling_factor=scn.cost_scaling_factor, inflation_radius=scn.inflation_radius)
+    f.seed(5)
+    uf, of = f.optimize(scn.tick, scn.u0)
+    assert np.array_equal(u2, uf) and np.array_equal(c2, f.get_costs())
+    assert o2.non_colliding == of.non_colliding
+
+    # a rolling window moves: new origin, same size -> whatever rows differ; a new size -> all
+    g.set_costmap(np.roll(cells, 3, axis=0), scn.origin_x, scn.origin_y + 3 * scn.resolution, scn.resolution)
+    assert 0 < g.costmap_upload_bytes()[0] <= full
+    small = cells[: M // 2, : M // 2]
+    g.set_costmap(small, scn.origin_x, scn.origin_y, scn.resolution)
+    assert g.costmap_upload_bytes()[0] == small.size
+    with pytest.raises(RuntimeError, match="region outside"):
+        g.update_costmap_region(cells, M // 2 - 2, 0, 4, 4)
