@@ -153,8 +153,8 @@ struct smpc_ctx {
   float* d_nvx = nullptr;
   float* d_nvy = nullptr;
   float* d_nwz = nullptr;
-  float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass
-  float* d_tvy = nullptr;
+  float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass:
+  float* d_tvy = nullptr;       // one allocation, vy and wz follow vx
   float* d_twz = nullptr;
   bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
@@ -272,7 +272,7 @@ void free_ctx(smpc_ctx* c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (float* p : {c->d_tvx, c->d_tvy, c->d_twz, c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
+  for (float* p : {c->d_tvx, c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
          c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
     if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
@@ -1175,11 +1175,13 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
       if (!strcmp(e, "lane")) tpr = true;
     }
     if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) tpr = false;   // visualisation path: wave pass
+    if (3ull * n >= (1ull << 32)) tpr = false;   // its buffer descriptor spans the three noise tensors
     c->use_tpr = tpr;
     if (tpr) {
-      CK(hipMalloc(&c->d_tvx, n));
-      CK(hipMalloc(&c->d_tvy, n));
-      CK(hipMalloc(&c->d_twz, n));
+      // back to back: the lane pass addresses the three through one buffer descriptor
+      CK(hipMalloc(&c->d_tvx, 3 * n));
+      c->d_tvy = c->d_tvx + n / sizeof(float);
+      c->d_twz = c->d_tvy + n / sizeof(float);
       CK(smpc_lane_set_lds_limit(static_cast<int>(kLdsPerCu)));
     }
   }

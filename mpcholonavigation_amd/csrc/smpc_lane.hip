@@ -274,10 +274,11 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   const uint32_t T = FULL ? 64u : p.T, B = p.B;
   // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
   // three tensors, the lane's own offset (b * 4) is the vector offset
-  const uint32_t noise_bytes = T * B * 4u;
-  const __amdgpu_buffer_rsrc_t rvx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvx), 0, noise_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rvy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvy), 0, noise_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rwz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.twz), 0, noise_bytes, 0x00020000);
+  // (the host lays the three [T,B] tensors out back to back: ONE descriptor, four scalar
+  // registers instead of twelve — the loop is short of them — and the tensor is part of the
+  // scalar offset)
+  const uint32_t noise_bytes = p.T * B * 4u;
+  const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvx), 0, 3u * noise_bytes, 0x00020000);
   const uint32_t row_bytes = B * 4u;
   const float dt = p.dt, yaw0 = p.yaw0;
   const double x0 = p.x0, y0 = p.y0;
@@ -374,6 +375,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       // index from the exact path; then ONE pair of dependent LDS reads serves every lane
       // and overlaps the sin/cos below.
       SmpcLut e = {0.f, 0.f};
+      uint32_t cell = 0;
       if (OBST) {
         const float qx = (x - p.wxf) * p.rinvf, qy = (y - p.wyf) * p.rinvf;
         const float rx = __builtin_amdgcn_fractf(qx), ry = __builtin_amdgcn_fractf(qy);
@@ -381,19 +383,30 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         const float lo = p.cell_eps_w, hi = 1.0f - p.cell_eps_w;
         const bool fast = (rx >= lo) & (rx <= hi) & (ry >= lo) & (ry <= hi) &
                           ((uint32_t)lx < (uint32_t)p.win_w) & ((uint32_t)ly < (uint32_t)p.win_h);
-        uint32_t idx = fast ? (uint32_t)(ly * p.win_w + lx) : 0u;
+        // window cells fit 24 bits: v_mad_u32_u24 (full rate) instead of a 64-bit multiply-add
+        uint32_t idx = fast ? __umul24((uint32_t)ly, (uint32_t)p.win_w) + (uint32_t)lx : 0u;
         if (__builtin_expect(__any(!fast), 0)) {
           if (!fast) idx = cell_byte_exact(p, s_map, x, y, (uint32_t)(wave * WAVE + lane));
         }
-        e = s_lut[s_map[idx]];
+        cell = s_map[idx];
       }
 
-      // cos_[t+1] = cos(yaw[t]); the last step's is never used
+      // cos_[t+1] = cos(yaw[t]); the last step's is never used.  It does not depend on the
+      // position, so it sits between the two dependent LDS reads of the lookup (cell byte,
+      // then the byte's table entry): the barrier keeps the scheduler from waiting for the
+      // byte right away.
       if (SAFE) {
         smpc_sincos(yaw, sn_prev, cs_prev);
       } else {
         yaw_max = fmaxf(yaw_max, fabsf(yaw));
         smpc_sincos_fast(yaw, sn_prev, cs_prev);
+      }
+      if (OBST) {
+        // (the empty asm pins the sin/cos here: left alone, the compiler sinks it into the next
+        // step, where it is first used, and waits for the byte with nothing to do)
+        asm volatile("" : "+v"(sn_prev), "+v"(cs_prev));
+        __builtin_amdgcn_sched_barrier(0);
+        e = s_lut[cell];
       }
       // PreferForwardCritic (prefer_forward_critic.cpp:42-46)
       pfw = fmaf(fmaxf(-vx, 0.f), dt, pfw);
@@ -462,17 +475,17 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     // noise, time-major: row t is a uniform base + this lane's offset; four steps in flight.
     // The control sequence of the next four steps is fetched (scalar loads) a quad ahead too.
     const uint32_t loff = bl * 4u;
-    auto ld = [&](const __amdgpu_buffer_rsrc_t r, uint32_t t) -> float {
+    auto ld = [&](uint32_t tensor, uint32_t t) -> float {
       const uint32_t tc = (FULL || t < T) ? t : T - 1;
-      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, loff, tc * row_bytes, 0));
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, loff, tensor * noise_bytes + tc * row_bytes, 0));
     };
     auto ldu = [&](uint32_t ctrl, uint32_t t) -> float {return cu[ctrl * T + (t < T ? t : T - 1)];};
     float nq[12], uq[12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      nq[3 * i + 0] = ld(rvx, i);
-      nq[3 * i + 1] = ld(rvy, i);
-      nq[3 * i + 2] = ld(rwz, i);
+      nq[3 * i + 0] = ld(0, i);
+      nq[3 * i + 1] = ld(1, i);
+      nq[3 * i + 2] = ld(2, i);
 #pragma unroll
       for (int k = 0; k < 3; ++k) uq[3 * i + k] = ldu(k, i);
     }
@@ -493,9 +506,9 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         // this step's noise; its registers are refilled at once with step t + 4
         const float n0 = nq[3 * i], n1 = nq[3 * i + 1], n2 = nq[3 * i + 2];
         if (q + 1 < nquad) {
-          nq[3 * i + 0] = ld(rvx, t + 4);
-          nq[3 * i + 1] = ld(rvy, t + 4);
-          nq[3 * i + 2] = ld(rwz, t + 4);
+          nq[3 * i + 0] = ld(0, t + 4);
+          nq[3 * i + 1] = ld(1, t + 4);
+          nq[3 * i + 2] = ld(2, t + 4);
         }
         cq[3 * i] = cq[3 * i + 1] = cq[3 * i + 2] = 0.f;
         if (FULL || t < T)
