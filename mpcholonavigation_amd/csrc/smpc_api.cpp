@@ -326,7 +326,8 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
 {
   SmpcLds L{};
   uint32_t o = with_map ? align_up(window_bytes, 16) : 0;
-  L.off_lut = o; o += with_map ? 256 * sizeof(SmpcLut) : 0;
+  // 256 entries + one all-zero entry (index 256: the lane pass primes its lookup pipeline with it)
+  L.off_lut = o; o += with_map ? (256 + 2) * sizeof(SmpcLut) : 0;
   const uint32_t pf = align_up(std::max(P, 1u) * 4, 16);
   L.off_px = o; o += pf;
   L.off_py = o; o += pf;

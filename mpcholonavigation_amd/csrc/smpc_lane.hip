@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         s_map[i] = p.map[(size_t)(p.win_y0 + ry) * p.W + p.win_x0 + rx];
       }
     }
-    for (int i = tid; i < 256; i += blockDim.x)
-      const_cast<SmpcLut*>(s_lut)[i] = p.lut[i];
+    for (int i = tid; i < 257; i += blockDim.x)
+      const_cast<SmpcLut*>(s_lut)[i] = i < 256 ? p.lut[i] : SmpcLut{0.f, 0.f};
     // one byte behind the window answers "off the map" (NO_INFORMATION,
     // obstacles_critic.cpp:209-212); behind it one byte per lane of every wave for costs
     // fetched from the global map (cells outside the window)
@@ -339,6 +339,13 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     float crit = 0.f, rep = 0.f;
     float yaw_max = 0.f;   // largest |yaw| seen (fast instance: range check of the sin/cos reduction)
     float alive = 1.0f;   // 1 until the rollout's first collision, then 0 (a float mask: fma(1, a, c) == c + a)
+    // The costmap lookup is two dependent LDS reads (the cell's byte, then the byte's table
+    // entry) feeding an in-order accumulation.  It runs as a pipeline two steps deep: step t
+    // issues the byte read of its own cell, the table read for the byte of step t - 1, and
+    // accumulates the entry of step t - 2 — every read has a whole step to complete, nothing
+    // waits.  Primed with the all-zero table entry 256; drained after the loop.
+    uint32_t cell_q = 256u;
+    SmpcLut e_q = {0.f, 0.f};
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     // PathAlign running state (path_align_critic.cpp:92-133)
     // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
@@ -374,9 +381,13 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       // rare lanes near a cell edge, outside the window or off the map get their LDS byte
       // index from the exact path; then ONE pair of dependent LDS reads serves every lane
       // and overlaps the sin/cos below.
-      SmpcLut e = {0.f, 0.f};
-      uint32_t cell = 0;
       if (OBST) {
+        // entry of step t - 2: steps after the first collision are never visited in the
+        // reference (masked)
+        alive = e_q.crit < 0.f ? 0.f : alive;   // inCollision
+        crit = fmaf(alive, e_q.crit, crit);
+        rep = fmaf(alive, e_q.rep, rep);
+        e_q = s_lut[cell_q];                    // byte of step t - 1
         const float qx = (x - p.wxf) * p.rinvf, qy = (y - p.wyf) * p.rinvf;
         const float rx = __builtin_amdgcn_fractf(qx), ry = __builtin_amdgcn_fractf(qy);
         const int lx = cvt_floor_i32(qx), ly = cvt_floor_i32(qy);
@@ -388,25 +399,15 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         if (__builtin_expect(__any(!fast), 0)) {
           if (!fast) idx = cell_byte_exact(p, s_map, x, y, (uint32_t)(wave * WAVE + lane));
         }
-        cell = s_map[idx];
+        cell_q = s_map[idx];
       }
 
-      // cos_[t+1] = cos(yaw[t]); the last step's is never used.  It does not depend on the
-      // position, so it sits between the two dependent LDS reads of the lookup (cell byte,
-      // then the byte's table entry): the barrier keeps the scheduler from waiting for the
-      // byte right away.
+      // cos_[t+1] = cos(yaw[t]); the last step's is never used
       if (SAFE) {
         smpc_sincos(yaw, sn_prev, cs_prev);
       } else {
         yaw_max = fmaxf(yaw_max, fabsf(yaw));
         smpc_sincos_fast(yaw, sn_prev, cs_prev);
-      }
-      if (OBST) {
-        // (the empty asm pins the sin/cos here: left alone, the compiler sinks it into the next
-        // step, where it is first used, and waits for the byte with nothing to do)
-        asm volatile("" : "+v"(sn_prev), "+v"(cs_prev));
-        __builtin_amdgcn_sched_barrier(0);
-        e = s_lut[cell];
       }
       // PreferForwardCritic (prefer_forward_critic.cpp:42-46)
       pfw = fmaf(fmaxf(-vx, 0.f), dt, pfw);
@@ -415,12 +416,6 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       gz = fmaf(uz, cwz - uz, gz);
       gy = fmaf(uy, cvy - uy, gy);
 
-      if (OBST) {
-        // steps after the first collision are never visited in the reference: masked
-        alive = e.crit < 0.f ? 0.f : alive;   // inCollision
-        crit = fmaf(alive, e.crit, crit);
-        rep = fmaf(alive, e.rep, rep);
-      }
       // PathAlignCritic sample (uniform in t): trajectory points step, 2 step, ...
       if (t == next_sample) {
         next_sample += step;
@@ -539,6 +534,15 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         PY1[8 * i + (q - 8)] = cq[3 * i + 1];
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
+    }
+    if (OBST) {   // drain the lookup pipeline: the entries of the last two steps
+      alive = e_q.crit < 0.f ? 0.f : alive;
+      crit = fmaf(alive, e_q.crit, crit);
+      rep = fmaf(alive, e_q.rep, rep);
+      e_q = s_lut[cell_q];
+      alive = e_q.crit < 0.f ? 0.f : alive;
+      crit = fmaf(alive, e_q.crit, crit);
+      rep = fmaf(alive, e_q.rep, rep);
     }
     // (a NaN yaw is sticky in the cumulative sum: the last one shows it)
     if (!SAFE && __builtin_expect(__any(!(yaw_max < 65536.0f) || !(fabsf(acc_yaw) < 65536.0f)), 0)) return true;
