@@ -236,13 +236,27 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     const int ww = p.win_w, wh = p.win_h;
     const bool vec = ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
     if (vec) {
-      const int w4 = ww >> 2;
-      for (int i = tid; i < w4 * wh; i += blockDim.x) {
+      // every thread's loads go out before the first store: one memory round trip for the
+      // whole window instead of one per pass of the loop
+      const int w4 = ww >> 2, n4 = w4 * wh;
+      auto word = [&](int i) -> uint32_t {
         const int ry = i / w4, rx = i - ry * w4;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(
-          p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0);
-        reinterpret_cast<uint32_t*>(s_map)[ry * w4 + rx] = src[rx];
+        return reinterpret_cast<const uint32_t*>(p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0)[rx];
+      };
+      constexpr int kAhead = 5;   // 96 x 96 bytes / 4 / 512 threads
+      uint32_t tmp[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const int i = tid + k * LANE_BLOCK;
+        tmp[k] = i < n4 ? word(i) : 0u;
       }
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const int i = tid + k * LANE_BLOCK;
+        if (i < n4) reinterpret_cast<uint32_t*>(s_map)[i] = tmp[k];
+      }
+      for (int i = tid + kAhead * LANE_BLOCK; i < n4; i += LANE_BLOCK)
+        reinterpret_cast<uint32_t*>(s_map)[i] = word(i);
     } else {
       for (int i = tid; i < ww * wh; i += blockDim.x) {
         const int ry = i / ww, rx = i - ry * ww;
