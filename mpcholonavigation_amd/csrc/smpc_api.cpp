@@ -332,7 +332,7 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
   L.off_px = o; o += pf;
   L.off_py = o; o += pf;
   L.off_pyaw = o; o += pf;
-  L.off_D = o; o += pf;
+  L.off_D = o; o += align_up((std::max(P, 1u) + 2) * 4, 16);   // + a sentinel on either side (lane pass)
   L.off_valid = o; o += align_up(std::max(P, 1u), 16);
   L.off_scr = o;
   // lanes per parked rollout: sample slots 0..nsamp fit one segment of 16/32/64 lanes;

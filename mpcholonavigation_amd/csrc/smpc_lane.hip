@@ -220,7 +220,9 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
   float* s_px = reinterpret_cast<float*>(smem + L.off_px);
   float* s_py = reinterpret_cast<float*>(smem + L.off_py);
-  float* s_D = reinterpret_cast<float*>(smem + L.off_D);
+  // cumulative path distances D[0..P-1) at s_D[0..], with a sentinel on either side of the
+  // part PathAlign searches: s_D[-1] = -3e38 and s_D[S] = +3e38 (S = furthest point)
+  float* s_D = reinterpret_cast<float*>(smem + L.off_D) + 1;
   uint8_t* s_valid = smem + L.off_valid;
 
   const int tid = threadIdx.x;
@@ -300,6 +302,12 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   if (p.flags & SD_NEED_FURTHEST) {
     S = p.d_furthest ? (uint32_t)(*p.d_furthest) : p.furthest_hint;
     if (S >= p.P) S = p.P ? p.P - 1 : 0;
+  }
+  // the sentinels of s_D (every wave writes the same two values before its first read: no
+  // second barrier, and S need not be known while the block stages)
+  if (lane == 0) {
+    s_D[-1] = -3.0e38f;
+    s_D[S] = 3.0e38f;
   }
   const bool pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && p.pa_active[S] && S > 0;
   float pf_x = 0.f, pf_y = 0.f;
@@ -448,9 +456,9 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         const float dist = traj_dist;
         uint32_t gi = (uint32_t)(dist * pa_inv_spacing);
         gi = gi < S ? gi : S - 1;
-        const float da = gi > 0 ? s_D[gi - 1] : -3.0e38f;
+        const float da = s_D[(int)gi - 1];     // the sentinels stand in at either end
         const float db = s_D[gi];
-        const float dc = gi + 1 < S ? s_D[gi + 1] : 3.0e38f;
+        const float dc = s_D[gi + 1];
         uint32_t lo;
         float dl, dh;
         const bool at_g = da < dist && !(db < dist);
