@@ -153,6 +153,7 @@ struct SmpcReduceArgs {
 // LDS carve-up, computed once on the host and passed to the kernel.
 struct SmpcLds {
   uint32_t off_lut, off_px, off_py, off_pyaw, off_D, off_valid, off_scr;
+  uint32_t off_pts4;    // lane pass: path points as {x, y, segment valid ? 1 : 0, 0} [P]
   uint32_t scr_stride;  // floats per wave of scratch
   uint32_t scr_pts;     // float offsets inside a wave's scratch: sample points [3][64],
   uint32_t scr_ring;    //   parked endpoints [2][64],

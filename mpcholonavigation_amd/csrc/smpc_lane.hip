@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   // cumulative path distances D[0..P-1) at s_D[0..], with a sentinel on either side of the
   // part PathAlign searches: s_D[-1] = -3e38 and s_D[S] = +3e38 (S = furthest point)
   float* s_D = reinterpret_cast<float*>(smem + L.off_D) + 1;
-  uint8_t* s_valid = smem + L.off_valid;
+  // PathAlign's view of the path: {x, y, segment valid ? 1 : 0, 0} per point, one 16-byte read
+  f32x4* s_pts4 = reinterpret_cast<f32x4*>(smem + L.off_pts4);
 
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
@@ -276,10 +277,9 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   for (uint32_t i = tid; i < p.P; i += blockDim.x) {
     s_px[i] = p.px[i];
     s_py[i] = p.py[i];
-    if (i + 1 < p.P) {
-      s_D[i] = p.D[i];
-      s_valid[i] = p.pvalid[i];
-    }
+    const bool seg = i + 1 < p.P;
+    if (seg) s_D[i] = p.D[i];
+    s_pts4[i] = f32x4{s_px[i], s_py[i], (seg && p.pvalid[i]) ? 1.0f : 0.f, 0.f};
   }
   __syncthreads();
 
@@ -459,16 +459,12 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         const float da = s_D[(int)gi - 1];     // the sentinels stand in at either end
         const float db = s_D[gi];
         const float dc = s_D[gi + 1];
-        uint32_t lo;
-        float dl, dh;
-        const bool at_g = da < dist && !(db < dist);
-        const bool at_g1 = db < dist && !(dc < dist);
-        if (at_g) {
-          lo = gi; dl = da; dh = db;
-        } else {
-          lo = gi + 1; dl = db; dh = dc;
-        }
-        if (__builtin_expect(__any(!(at_g || at_g1)), 0)) {
+        // D is non-decreasing, so (da < dist) >= (db < dist) >= (dc < dist): the lower bound
+        // is g or g + 1 exactly when the first holds and the last does not
+        const bool c0 = da < dist, c1 = db < dist, c2 = dc < dist;
+        uint32_t lo = gi + (c1 ? 1u : 0u);
+        float dl = c1 ? db : da, dh = c1 ? dc : db;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!c0 || c2) != 0, 0)) {
           uint32_t base = 0, nn = S;
           for (uint32_t it = 0; it < bs_iters; ++it) {
             const uint32_t half = nn >> 1;
@@ -486,11 +482,11 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         else if (lo >= S) pt = S - 1;              // end(): defined as size-1
         else pt = (dist - dl < dh - dist) ? lo - 1 : lo;
         path_pt = pt;
-        const bool ok = s_valid[pt] != 0;
-        const float ex = s_px[pt] - x, ey = s_py[pt] - y;
+        const f32x4 q = s_pts4[pt];
+        const float ex = q[0] - x, ey = q[1] - y;
         const float d = fast_sqrt(ex * ex + ey * ey);
-        pa_num += ok ? 1.0f : 0.f;
-        pa_sum += ok ? d : 0.f;
+        pa_num += q[2];                  // segment valid ? 1 : 0 (path_align_critic.cpp:119-127)
+        pa_sum = fmaf(q[2], d, pa_sum);
       }
     };
 
