@@ -828,6 +828,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
   c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
+  // the lane pass samples PathAlign's trajectory points at the first step of every quad:
+  // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
+  if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
   if (c->lane_now) {
     const SmpcLds Lt = lane_lds(window_bytes, P, T);
     c->lane_window_bytes = window_bytes;

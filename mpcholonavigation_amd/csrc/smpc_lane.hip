@@ -320,7 +320,6 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   float pa_inv_spacing = 0.f;
   if (pa_on && S > 1 && p.D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / p.D[S - 1];
   const bool want_local_furthest = (p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST);
-  const uint32_t step = p.step;
   const uint32_t nquad = (T + 3u) >> 2;
 
   // ---- per-wave running softmax state; U[ctrl][t] lives in lane t ----------------
@@ -373,10 +372,10 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
     float traj_dist = 0.f, pa_sum = 0.f, pa_num = 0.f, sx_prev = p.x00f, sy_prev = p.y00f;
     uint32_t path_pt = 0;
-    uint32_t next_sample = (pa_on && step) ? step : 0xffffffffu;
 
     // one time step for the 64 rollouts of this wave; t, ux, uy, uz are wave-uniform
-    auto do_step = [&](const uint32_t t, const float ux, const float uy, const float uz,
+    // sample_slot: this step is a multiple of four (known at compile time in the unrolled quad)
+    auto do_step = [&](const uint32_t t, const bool sample_slot, const float ux, const float uy, const float uz,
                        const float n0, const float n1, const float n2, float& cvx, float& cvy,
                        float& cwz) {
       // NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74)
@@ -444,8 +443,10 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       gy = fmaf(uy, cvy - uy, gy);
 
       // PathAlignCritic sample (uniform in t): trajectory points step, 2 step, ...
-      if (t == next_sample) {
-        next_sample += step;
+      // (trajectory_point_step is 4 here, the reference's default — the host sends any other
+      // value to the wave-per-rollout pass — so the sample steps are the first of every quad
+      // but the very first: no per-step bookkeeping, no branch in the other three steps)
+      if (sample_slot && pa_on && t != 0) {
         const float ddx = x - sx_prev, ddy = y - sy_prev;
         traj_dist += fast_sqrt(ddx * ddx + ddy * ddy);
         sx_prev = x;
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         }
         cq[3 * i] = cq[3 * i + 1] = cq[3 * i + 2] = 0.f;
         if (FULL || t < T)
-          do_step(t, uc[3 * i], uc[3 * i + 1], uc[3 * i + 2], n0, n1, n2, cq[3 * i], cq[3 * i + 1],
+          do_step(t, i == 0, uc[3 * i], uc[3 * i + 1], uc[3 * i + 2], n0, n1, n2, cq[3 * i], cq[3 * i + 1],
                   cq[3 * i + 2]);
       }
     };
