@@ -421,8 +421,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         const bool fast = (edge <= 0.5f - p.cell_eps_w) &
                           ((uint32_t)lx < (uint32_t)p.win_w) & ((uint32_t)ly < (uint32_t)p.win_h);
         // window cells fit 24 bits: v_mad_u32_u24 (full rate) instead of a 64-bit multiply-add
-        uint32_t idx = fast ? __umul24((uint32_t)ly, (uint32_t)p.win_w) + (uint32_t)lx : 0u;
-        if (__builtin_expect(__any(!fast), 0)) {
+        uint32_t idx = __umul24((uint32_t)ly, (uint32_t)p.win_w) + (uint32_t)lx;   // (meaningless if !fast)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0, 0)) {
           if (!fast) idx = cell_byte_exact(p, s_map, x, y, (uint32_t)(wave * WAVE + lane));
         }
         cell_q = s_map[idx];
