@@ -187,6 +187,7 @@ struct smpc_ctx {
   hipEvent_t ev_map = nullptr;       // behind the last costmap upload
   bool map_pending = false;          // that upload may still be reading the pinned mirror
   uint64_t map_bytes_last = 0, map_bytes_total = 0;   // uploaded by the last call / so far
+  unsigned long long* d_timeline = nullptr;   // SMPC_LANE_TIMELINE=1 (developer aid)
   // per-tick block
   SmpcLut* d_lut = nullptr;
   SmpcLut* h_lut = nullptr;     // pinned
@@ -276,6 +277,7 @@ void free_ctx(smpc_ctx* c)
          c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
     if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
+  if (c->d_timeline) (void)hipFree(c->d_timeline);
   if (c->map.cells) (void)hipHostFree(c->map.cells);
   if (c->ev_map) (void)hipEventDestroy(c->ev_map);
   if (c->d_tick && !c->defer_upload) (void)hipFree(c->d_tick);
@@ -786,6 +788,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
   d.neg_inv_temp = -1 / c->cfg.temperature;
   d.k2 = d.neg_inv_temp * 1.4426950408889634f;
+  d.timeline = c->d_timeline;
   d.partials = c->d_partials;
   d.furthest_out = reinterpret_cast<uint32_t*>(c->d_furthest);
 
@@ -1159,6 +1162,10 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   c->poll_enabled = getenv("SMPC_NO_POLL") == nullptr;
+  if (getenv("SMPC_LANE_TIMELINE")) {
+    CK(hipMalloc(&c->d_timeline, (8192 + kMaxGrid * 8) * sizeof(unsigned long long)));
+    CK(hipMemset(c->d_timeline, 0, (8192 + kMaxGrid * 8) * sizeof(unsigned long long)));
+  }
   CK(hipEventCreate(&c->ev0));
   CK(hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev1));
@@ -1617,6 +1624,42 @@ int smpc_set_stream(smpc_ctx* c, void* hip_stream)
   const int rc = wait_map_upload(c);   // it went out on the stream being left
   if (rc != SMPC_OK) return rc;
   c->stream = hip_stream == SMPC_STREAM_OWN ? c->own_stream : static_cast<hipStream_t>(hip_stream);
+  return SMPC_OK;
+}
+
+// developer aid: stage durations of the last lane-pass launch, from the stamps of wave 0 of
+// every block (shader clocks; stages: entry -> LDS staged -> constants -> group 1 -> group 2
+// -> all waves at the final barrier -> partial written); out[7][3] = min, median, max
+int smpc_debug_lane_timeline(smpc_ctx* c, double* out, uint32_t* n_blocks)
+{
+  if (!c || !out || !c->d_timeline) return SMPC_ERR_INVALID;
+  HIPCK(c, hipSetDevice(c->device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const uint32_t nb = c->grid_tpr;
+  std::vector<unsigned long long> h(static_cast<size_t>(nb) * 8);
+  HIPCK(c, hipMemcpy(h.data(), c->d_timeline, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull;
+  for (uint32_t b = 0; b < nb; ++b) t0 = std::min(t0, h[b * 8]);
+  for (int k = 0; k < 7; ++k) {
+    std::vector<double> v;
+    for (uint32_t b = 0; b < nb; ++b)
+      if (h[b * 8 + k]) v.push_back(static_cast<double>(h[b * 8 + k] - (k ? h[b * 8 + k - 1] : t0)));
+    std::sort(v.begin(), v.end());
+    out[3 * k] = v.empty() ? 0 : v.front();
+    out[3 * k + 1] = v.empty() ? 0 : v[v.size() / 2];
+    out[3 * k + 2] = v.empty() ? 0 : v.back();
+  }
+  // out[21..28]: per wave of the block, median of (end of its groups - stamp 2 of wave 0)
+  std::vector<unsigned long long> hw(static_cast<size_t>(nb) * 8);
+  HIPCK(c, hipMemcpy(hw.data(), c->d_timeline + 8192, hw.size() * sizeof(hw[0]), hipMemcpyDeviceToHost));
+  for (int w = 0; w < 8; ++w) {
+    std::vector<double> v;
+    for (uint32_t b = 0; b < nb; ++b)
+      if (hw[b * 8 + w] && h[b * 8 + 2]) v.push_back(static_cast<double>(hw[b * 8 + w] - h[b * 8 + 2]));
+    std::sort(v.begin(), v.end());
+    out[21 + w] = v.empty() ? 0 : v[v.size() / 2];
+  }
+  if (n_blocks) *n_blocks = nb;
   return SMPC_OK;
 }
 

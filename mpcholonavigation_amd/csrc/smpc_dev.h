@@ -127,6 +127,8 @@ struct SmpcDev {
   // outputs
   float* partials;         // [gridDim.x][4 + 3T] per-block softmax partials
   uint32_t* furthest_out;  // atomicMax target of the furthest-only pass (float bits)
+  // developer aid (SMPC_LANE_TIMELINE=1): [gridDim.x][8] shader-clock stamps of the lane pass
+  unsigned long long* timeline;
 };
 
 // optional finishing step of smpc_reduce_partials (single tuple -> new control sequence)

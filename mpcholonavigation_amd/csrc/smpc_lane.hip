@@ -230,6 +230,12 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwave = blockDim.x >> 6;
+  // developer aid: shader-clock stamps of wave 0 (null pointer: one uniform branch each)
+  auto stamp = [&](int k) {
+    if (__builtin_expect(p.timeline != nullptr, 0) && tid == 0)
+      p.timeline[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   // per wave: [64][65] parked wz, [64] softmax weights; the head is re-used by the block combine
   float* park = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
   float* s_w = park + 64 * LANE_PARK_STRIDE;
@@ -282,6 +288,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     s_pts4[i] = f32x4{s_px[i], s_py[i], (seg && p.pvalid[i]) ? 1.0f : 0.f, 0.f};
   }
   __syncthreads();
+  stamp(1);
 
   // ---- constants (wave-uniform: scalar registers) -------------------------------
   // u and the path are inputs of the launch: read them through the constant address space,
@@ -508,8 +515,18 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
 #pragma unroll
       for (int k = 0; k < 3; ++k) uq[3 * i + k] = ldu(k, i);
     }
+    uint64_t clk = __builtin_amdgcn_s_memtime();
     // four steps; returns their noised controls cq[3 i + ctrl]
     auto run_quad = [&](const uint32_t q, float (&cq)[12]) {
+      // The two waves of a SIMD do not share it evenly by themselves: the older one wins every
+      // tie and finishes its groups ~25 % sooner (41 us against 51 us for two groups), then the
+      // younger one runs alone.  Swapping their priorities every 2^15 shader clocks — by the clock,
+      // read a quad earlier: the same for both whatever their progress, in anti-phase between
+      // waves w and w + 4 — lets both finish together at 47 us (measured: tools/lane_timeline.py;
+      // shorter periods share less evenly, 2^12: 45 / 48 us).
+      if (((uint32_t)(clk >> 15) + (uint32_t)(wave >> 2)) & 1u) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      clk = __builtin_amdgcn_s_memtime();
       float uc[12];
 #pragma unroll
       for (int j = 0; j < 12; ++j) uc[j] = uq[j];
@@ -677,12 +694,18 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     return false;
   };
 
+  stamp(2);
+  int stamp_k = 3;
   for (uint32_t grp = gw; grp < ngroups; grp += nW) {
     if (__builtin_expect(group_body(std::false_type{}, grp), 0)) group_body(std::true_type{}, grp);
+    if (stamp_k < 5) stamp(stamp_k++);
   }
 
+  if (__builtin_expect(p.timeline != nullptr, 0) && lane == 0)
+    p.timeline[8192 + blockIdx.x * 8 + wave] = __builtin_amdgcn_s_memtime();
   // ---- block combine -> one partial per block (same tuple as the wave-per-rollout pass)
   __syncthreads();
+  stamp(5);
   const uint32_t TL = 4 + 3 * T;
   float* myp = reinterpret_cast<float*>(smem + L.off_scr) + (size_t)wave * L.scr_stride;
   if (lane == 0) {
@@ -718,6 +741,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     }
     outp[i] = acc;
   }
+  stamp(6);
 }
 
 hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st)
