@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     } else {
       for (int w = 0; w < nwave; ++w) {
         const float mw = allp[(size_t)w * L.scr_stride];
-        const float sc = expf(p.neg_inv_temp * (mw - bm));
+        const float sc = __builtin_amdgcn_exp2f(p.k2 * (mw - bm));   // as the per-wave rescale above
         acc += sc * allp[(size_t)w * L.scr_stride + i];
       }
     }
