@@ -241,24 +241,31 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   float* s_w = park + 64 * LANE_PARK_STRIDE;
 
   // ---- stage costmap window, LUT and path into LDS -------------------------
-  if (OBST) {
-    const int ww = p.win_w, wh = p.win_h;
-    const bool vec = ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
-    if (vec) {
-      // every thread's loads go out before the first store: one memory round trip for the
-      // whole window instead of one per pass of the loop
-      const int w4 = ww >> 2, n4 = w4 * wh;
-      auto word = [&](int i) -> uint32_t {
-        const int ry = i / w4, rx = i - ry * w4;
-        return reinterpret_cast<const uint32_t*>(p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0)[rx];
-      };
-      constexpr int kAhead = 5;   // 96 x 96 bytes / 4 / 512 threads
-      uint32_t tmp[kAhead];
+  // Every global load of the staging goes out before the first LDS store (one memory round trip
+  // for window, table and path together); what exceeds one pass of the block is looped over
+  // afterwards.
+  {
+    const int ww = OBST ? p.win_w : 0, wh = OBST ? p.win_h : 0;
+    const bool vec = OBST && ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
+    const int w4 = ww >> 2, n4 = vec ? w4 * wh : 0;
+    auto word = [&](int i) -> uint32_t {
+      const int ry = i / w4, rx = i - ry * w4;
+      return reinterpret_cast<const uint32_t*>(p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0)[rx];
+    };
+    constexpr int kAhead = 5;   // 96 x 96 bytes / 4 / 512 threads
+    uint32_t tmp[kAhead];
 #pragma unroll
-      for (int k = 0; k < kAhead; ++k) {
-        const int i = tid + k * LANE_BLOCK;
-        tmp[k] = i < n4 ? word(i) : 0u;
-      }
+    for (int k = 0; k < kAhead; ++k) {
+      const int i = tid + k * LANE_BLOCK;
+      tmp[k] = i < n4 ? word(i) : 0u;
+    }
+    const SmpcLut lut_e = (OBST && tid < 256) ? p.lut[tid] : SmpcLut{0.f, 0.f};
+    const bool pt_on = (uint32_t)tid < p.P, seg_on = (uint32_t)tid + 1 < p.P;
+    const float g_px = pt_on ? p.px[tid] : 0.f, g_py = pt_on ? p.py[tid] : 0.f;
+    const float g_D = seg_on ? p.D[tid] : 0.f;
+    const bool g_valid = seg_on && p.pvalid[tid] != 0;
+
+    if (OBST) {
 #pragma unroll
       for (int k = 0; k < kAhead; ++k) {
         const int i = tid + k * LANE_BLOCK;
@@ -266,26 +273,33 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       }
       for (int i = tid + kAhead * LANE_BLOCK; i < n4; i += LANE_BLOCK)
         reinterpret_cast<uint32_t*>(s_map)[i] = word(i);
-    } else {
-      for (int i = tid; i < ww * wh; i += blockDim.x) {
-        const int ry = i / ww, rx = i - ry * ww;
-        s_map[i] = p.map[(size_t)(p.win_y0 + ry) * p.W + p.win_x0 + rx];
+      if (!vec) {
+        for (int i = tid; i < ww * wh; i += blockDim.x) {
+          const int ry = i / ww, rx = i - ry * ww;
+          s_map[i] = p.map[(size_t)(p.win_y0 + ry) * p.W + p.win_x0 + rx];
+        }
       }
+      if (tid < 257) const_cast<SmpcLut*>(s_lut)[tid] = lut_e;   // [256] is the all-zero entry
+      // one byte behind the window answers "off the map" (NO_INFORMATION,
+      // obstacles_critic.cpp:209-212); behind it one byte per lane of every wave for costs
+      // fetched from the global map (cells outside the window)
+      if (tid == 0) s_map[ww * wh] = 255;
     }
-    for (int i = tid; i < 257; i += blockDim.x)
-      const_cast<SmpcLut*>(s_lut)[i] = i < 256 ? p.lut[i] : SmpcLut{0.f, 0.f};
-    // one byte behind the window answers "off the map" (NO_INFORMATION,
-    // obstacles_critic.cpp:209-212); behind it one byte per lane of every wave for costs
-    // fetched from the global map (cells outside the window)
-    if (tid == 0) s_map[ww * wh] = 255;
-  }
-  for (uint32_t i = p.P + tid; i < ((p.P + 3u) & ~3u); i += blockDim.x) s_px[i] = s_py[i] = 1.0e18f;
-  for (uint32_t i = tid; i < p.P; i += blockDim.x) {
-    s_px[i] = p.px[i];
-    s_py[i] = p.py[i];
-    const bool seg = i + 1 < p.P;
-    if (seg) s_D[i] = p.D[i];
-    s_pts4[i] = f32x4{s_px[i], s_py[i], (seg && p.pvalid[i]) ? 1.0f : 0.f, 0.f};
+    for (uint32_t i = p.P + tid; i < ((p.P + 3u) & ~3u); i += blockDim.x) s_px[i] = s_py[i] = 1.0e18f;
+    if (pt_on) {
+      s_px[tid] = g_px;
+      s_py[tid] = g_py;
+      if (seg_on) s_D[tid] = g_D;
+      s_pts4[tid] = f32x4{g_px, g_py, g_valid ? 1.0f : 0.f, 0.f};
+    }
+    for (uint32_t i = tid + LANE_BLOCK; i < p.P; i += LANE_BLOCK) {   // paths beyond 512 points
+      const float qx = p.px[i], qy = p.py[i];
+      const bool seg = i + 1 < p.P;
+      s_px[i] = qx;
+      s_py[i] = qy;
+      if (seg) s_D[i] = p.D[i];
+      s_pts4[i] = f32x4{qx, qy, (seg && p.pvalid[i]) ? 1.0f : 0.f, 0.f};
+    }
   }
   __syncthreads();
   stamp(1);
