@@ -605,29 +605,35 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     // ================= per-rollout epilogue, lane = rollout ==============================
     // nearest path point of the endpoint (utils.hpp:292-319): first minimum wins
     if (want_local_furthest) {
-      float best = 3.4028234663852886e38f;
-      uint32_t bi = 0;
-      // four path points per pair of LDS broadcast reads; the arrays are padded to a
-      // multiple of four with far-away points that never win
-      const uint32_t P4 = (p.P + 3u) & ~3u;
-      for (uint32_t j = 0; j < P4; j += 4) {
-        const f32x4 qx = *reinterpret_cast<const f32x4*>(s_px + j);
-        const f32x4 qy = *reinterpret_cast<const f32x4*>(s_py + j);
-        // squared distances two at a time (packed f32), then the reference's strict "<" scan
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 xx = {x, x}, yy = {y, y};
-        const f32x2 ax0 = f32x2{qx[0], qx[1]} - xx, ay0 = f32x2{qy[0], qy[1]} - yy;
-        const f32x2 ax1 = f32x2{qx[2], qx[3]} - xx, ay1 = f32x2{qy[2], qy[3]} - yy;
-        const f32x2 d0 = ax0 * ax0 + ay0 * ay0, d1 = ax1 * ax1 + ay1 * ay1;
-        const float dd[4] = {d0[0], d0[1], d1[0], d1[1]};
+      // Four path points per pair of LDS broadcast reads (the arrays are padded to a multiple
+      // of four with far-away points that never win).  The strict "<" scan runs over the
+      // MINIMUM of each block of four — the first block that holds the overall minimum wins —
+      // and the first point of that block that attains it is found afterwards, from the same
+      // arithmetic: the reference's first minimum at a third of the compare/select work.
+      auto block_d2 = [&](const float* bx, const float* by, float (&dd)[4]) {
+        const f32x4 qx = *reinterpret_cast<const f32x4*>(bx);
+        const f32x4 qy = *reinterpret_cast<const f32x4*>(by);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (dd[e] < best) {
-            best = dd[e];
-            bi = j + e;
-          }
+          const float ex = qx[e] - x, ey = qy[e] - y;
+          dd[e] = ex * ex + ey * ey;
+        }
+      };
+      float best = 3.4028234663852886e38f;
+      uint32_t bj = 0;
+      const uint32_t P4 = (p.P + 3u) & ~3u;
+      for (uint32_t j = 0; j < P4; j += 4) {
+        float dd[4];
+        block_d2(s_px + j, s_py + j, dd);
+        const float mn = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
+        if (mn < best) {      // a NaN or infinite distance never wins, as in the plain scan
+          best = mn;
+          bj = j;
         }
       }
+      float dd[4];
+      block_d2(s_px + bj, s_py + bj, dd);
+      const uint32_t bi = bj + (dd[0] == best ? 0u : dd[1] == best ? 1u : dd[2] == best ? 2u : dd[3] == best ? 3u : 0u);
       uint32_t m = live ? bi : 0u;
       for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, WAVE));
       S_local = max(S_local, m);
