@@ -99,7 +99,7 @@ const RcclApi* rccl()
 // threads per block of the streaming pass: 16 waves share one costmap window and produce one
 // partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
 inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
-constexpr uint32_t kLaneMinBatch = 128u * 1024u;  // lane-per-rollout pass from this batch size up (measured crossover ~100k)
+constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
 constexpr uint32_t kLaneMaxT = 64;        // it parks 3 x 64 noised controls per lane in registers
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
