@@ -1,0 +1,274 @@
+// smpc_ctx.h — what the translation units behind include/smpc.h share: the context object,
+// the launchers of the .hip files, and the host-side helpers (smpc_impl).  Internal: not part of
+// the C-ABI.
+//   smpc_api.cpp      lifecycle, setters, the single-GPU tick (smpc_optimize), launch helpers
+//   smpc_prepare.cpp  per-tick host work: gates, path tables, lookup tables, LDS carve-up
+//   smpc_shard.cpp    batch-sharded tick, RCCL resolved at run time
+//   smpc_group.cpp    several planning instances per launch
+#ifndef SMPC_CTX_H_
+#define SMPC_CTX_H_
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: RCCL itself is resolved at run time (dlopen)
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/smpc.h"
+#include "smpc_dev.h"
+
+// nothing below is part of the C-ABI: keep it out of the dynamic symbol table
+#pragma GCC visibility push(hidden)
+
+hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
+                            uint32_t grid, uint32_t block, hipStream_t st);
+hipError_t smpc_pass_occupancy(int R, int mode, bool full, uint32_t block, uint32_t lds_bytes,
+                               int* blocks_per_cu);
+hipError_t smpc_set_pass_lds_limit(int bytes);
+hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
+                              float neg_inv_temp, float* tuple, const SmpcFinal& fin,
+                              hipStream_t st);
+hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, float neg_inv_temp,
+                               float vx_max, float vx_min, float vy_max, float wz_max,
+                               float* u_out, float* result, const float* furthest_used,
+                               float* host_out, uint32_t seq, hipStream_t st);
+hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
+                                  uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
+hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float min_r, uint32_t seq,
+                                 hipStream_t st);
+
+hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st);
+uint32_t smpc_lane_block();
+hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu);
+hipError_t smpc_lane_set_lds_limit(int bytes);
+hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
+hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
+                                      const SmpcLds& L, uint32_t grid, hipStream_t st);
+hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
+                                   float neg_inv_temp, hipStream_t st);
+hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
+
+namespace smpc_impl {
+
+extern thread_local std::string g_create_error;
+
+
+// RCCL entry points, resolved once.  The library is not a link-time dependency: a process
+// that already holds RCCL (torch.distributed's "nccl" backend IS RCCL on ROCm) shares that
+// copy, a single-GPU user never loads it.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+const RcclApi* rccl();   // smpc_shard.cpp; null when RCCL cannot be loaded
+
+// threads per block of the streaming pass: 16 waves share one costmap window and produce one
+// partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
+inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
+constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
+constexpr uint32_t kLaneMaxT = 64;        // it parks 3 x 64 noised controls per lane in registers
+constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
+constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
+                                           // 0.05 m around the robot; the rest is read from HBM/L2
+constexpr uint32_t kLdsPerCu = 160 * 1024;
+
+inline uint32_t align_up(uint32_t v, uint32_t a) {return (v + a - 1) / a * a;}
+
+struct HostCostmap {
+  uint8_t* cells = nullptr;   // pinned mirror of the device copy: the host-side lookups read it
+  size_t cap = 0;             // (path validity, first rollout point) and uploads DMA out of it
+  uint32_t W = 0, H = 0;
+  double ox = 0, oy = 0, res = 1;
+  bool track_unknown = false;
+  float inscribed_radius = 0, cost_scaling_factor = 0, inflation_radius = 0;
+  bool set = false;
+};
+
+// Costmap2D::worldToMap (nav2_costmap_2d, Humble); call sites tools/utils.hpp:365-372
+inline bool world_to_map(const HostCostmap& c, double wx, double wy, unsigned& mx, unsigned& my)
+{
+  if (wx < c.ox || wy < c.oy) return false;
+  const double qx = (wx - c.ox) / c.res, qy = (wy - c.oy) / c.res;
+  if (!(qx < 4294967296.0) || !(qy < 4294967296.0)) return false;
+  mx = static_cast<unsigned>(qx);
+  my = static_cast<unsigned>(qy);
+  return mx < c.W && my < c.H;
+}
+
+// utils::withinPositionGoalTolerance(float, Pose, Pose) (tools/utils.hpp:233-249)
+inline bool within_tol(float tol, double rx, double ry, double gx, double gy)
+{
+  const double dist_sq = std::pow(gx - rx, 2) + std::pow(gy - ry, 2);
+  const float tol_sq = tol * tol;
+  return dist_sq < tol_sq;
+}
+
+}  // namespace smpc_impl
+
+struct smpc_ctx {
+  smpc_config cfg{};
+  smpc_critic_params critics{};
+  float c_vx_max = 0, c_vx_min = 0, c_vy = 0, c_wz = 0;
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evp[8] = {};   // SMPC_FLAG_PROFILE: pairs around up to 4 scoring passes
+  uint32_t evp_used = 0;
+  // tensors
+  float* d_nvx = nullptr;
+  float* d_nvy = nullptr;
+  float* d_nwz = nullptr;
+  float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass:
+  float* d_tvy = nullptr;       // one allocation, vy and wz follow vx
+  float* d_twz = nullptr;
+  bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
+  bool lane_now = false;     // ... and does for this tick (lean scoring mode)
+  uint32_t last_pass_kind = 0;
+  // member of a smpc_group: the group uploads every member's tick block in one copy
+  bool defer_upload = false;
+  uint32_t lane_window_bytes = 0;   // first LDS region of the lane pass this tick
+  // consider_footprint: robot footprint (smpc_set_footprint) and the LUT pair built for it
+  std::vector<double> fp_x, fp_y;
+  double fp_circumscribed_radius = 0.0, fp_layer_scale = -1.0;
+  SmpcLut* d_lut_fp = nullptr;   // [2][256]
+  SmpcLut* h_lut_fp = nullptr;   // pinned
+  // native RCCL exchange of the batch-sharded tick (smpc_shard_tick)
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  float* d_all = nullptr;     // [world][4 + 3T] gathered shard tuples
+  SmpcLds lds_tpr{};
+  uint32_t grid_tpr = 0;
+  uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
+  float* d_costs[2] = {nullptr, nullptr};
+  float* d_traj[3] = {nullptr, nullptr, nullptr};
+  int costs_cur = 0;
+  bool have_noise = false, rng_mode = false;
+  uint64_t seed = 0;
+  uint32_t epoch = 0;
+  // costmap
+  smpc_impl::HostCostmap map;
+  uint8_t* d_map = nullptr;
+  size_t d_map_bytes = 0;
+  hipEvent_t ev_map = nullptr;       // behind the last costmap upload
+  bool map_pending = false;          // that upload may still be reading the pinned mirror
+  uint64_t map_bytes_last = 0, map_bytes_total = 0;   // uploaded by the last call / so far
+  unsigned long long* d_timeline = nullptr;   // SMPC_LANE_TIMELINE=1 (developer aid)
+  // per-tick block
+  SmpcLut* d_lut = nullptr;
+  SmpcLut* h_lut = nullptr;     // pinned
+  uint64_t lut_key = 0, map_version = 1, critics_version = 1;
+  bool lut_valid = false;
+  uint8_t* d_tick = nullptr;
+  uint8_t* h_tick = nullptr;  // pinned
+  size_t tick_cap = 0;
+  // reductions / outputs
+  float* d_partials = nullptr;
+  float* d_tuple = nullptr;
+  float* d_out = nullptr;       // [3T u][8 result]
+  float* h_out = nullptr;       // pinned, device-mapped: kernels write the result here
+  float* h_out_dev = nullptr;   // its device-side address
+  float* d_furthest = nullptr;  // one float (atomicMax on its bits)
+  // launch geometry
+  int R = 1;
+  uint32_t grid = 0;
+  SmpcLds lds{};
+  // per-tick prepared state
+  SmpcDev dev{};
+  uint32_t gate_flags = 0;   // critics past their host-side gates this tick
+  int score_mode = 0;        // 0: every cost_power == 1 (one fused reduction), 2: general
+  uint32_t occ_blocks = 1, occ_lds = 0xffffffffu;
+  int occ_mode = -1;
+  static int score_mode_for(const smpc_critic_params& cr)
+  {
+    return (cr.obstacles.cost_power == 1 && cr.path_align.cost_power == 1 &&
+           cr.path_follow.cost_power == 1 && cr.goal_angle.cost_power == 1 &&
+           cr.prefer_forward.cost_power == 1) ? 0 : 2;
+  }
+  bool tick_ready = false;
+  bool fail_in = false;
+  uint32_t P = 0;
+  uint32_t passes = 0;
+  // speculation on furthest_reached_path_point: last tick's value
+  bool hint_valid = false;
+  uint32_t hint = 0;
+  uint64_t spec_misses = 0;
+  // completion polling on the host-mapped result (SMPC_NO_POLL=1 disables)
+  bool poll_enabled = true;
+  // Optimizer::isHolonomic (optimizer.cpp:235).  A non-holonomic model is the Omni data path
+  // with the vy noise, control_sequence.vy and state.vy[:,0] all zero: then state.vy = 0,
+  // dx = vx cos - 0 sin, the vy gamma term and the weighted vy update are exactly 0 — what the
+  // reference's isHolonomic() branches compute (optimizer.cpp:220-224,241-243,264-266,334-337,
+  // 374-389), without a second set of kernels.
+  bool holonomic = true;
+  float acker_r = -1.f;      // Ackermann min_turning_r, < 0 for the other models
+  uint32_t acker_seq = 0;    // completion word the Ackermann launch publishes this tick
+  uint32_t seq = 0, poll_seq = 0;
+  std::string err;
+};
+
+namespace smpc_impl {
+
+int fail(smpc_ctx* c, int code, const std::string& msg);
+
+#define HIPCK(ctx, call)                                                               \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return fail(ctx, SMPC_ERR_DEVICE,                                                \
+                  std::string(#call) + ": " + hipGetErrorString(e__));                \
+  } while (0)
+
+int wait_map_upload(smpc_ctx* c);
+void free_ctx(smpc_ctx* c);
+
+// tick block layout (offsets in bytes), sized for the ctx's T and SMPC_MAX_PATH
+struct TickLayout {
+  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, pang_active, lut_cost, total;
+};
+TickLayout tick_layout(uint32_t T, uint32_t P);
+
+// LDS carve-up of the streaming pass.  nsamp = PathAlign samples per rollout (0: off).
+SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
+                 uint32_t nsamp = 0);
+SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T);
+
+int check_tick(smpc_ctx* c, const smpc_tick_in* in);
+int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in);
+
+int launch_furthest(smpc_ctx* c, float* d_furthest);
+void fill_score_args(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
+                     uint32_t furthest_hint, bool finish, const float* finish_furthest, SmpcDev& d,
+                     SmpcFinal& fin);
+int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d_furthest,
+                 uint32_t furthest_hint, float* d_tuple, bool finish = false,
+                 const float* finish_furthest = nullptr);
+int launch_combine(smpc_ctx* c, const float* d_tuples, uint32_t n, const float* d_furthest_used);
+void store_control_sequence(const smpc_ctx* c, float* u_inout);
+int fetch_out(smpc_ctx* c);
+float profile_pass_ms(smpc_ctx* c);
+uint32_t fail_only_flags(const smpc_ctx* c);
+uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky);
+int update_time_major(smpc_ctx* c);
+int draw_noise(smpc_ctx* c);
+
+}  // namespace smpc_impl
+
+#pragma GCC visibility pop
+
+#endif  // SMPC_CTX_H_

@@ -1,0 +1,580 @@
+// smpc_prepare.cpp — the per-tick host work behind the C-ABI (include/smpc.h): what the
+// reference's critics do once per tick (goal-distance gates, path validity, cumulative path
+// lengths, the per-candidate PathAlign / PathFollow tables), the 256-entry lookup tables of
+// the collision critics, the tick block the kernels read, and the LDS carve-up of the passes.
+#include "smpc_ctx.h"
+
+namespace smpc_impl {
+
+TickLayout tick_layout(uint32_t T, uint32_t P)
+{
+  TickLayout l{};
+  size_t o = 0;
+  l.u = o; o += align_up(3 * T * 4, 16);
+  l.px = o; o += align_up(P * 4, 16);
+  l.py = o; o += align_up(P * 4, 16);
+  l.pyaw = o; o += align_up(P * 4, 16);
+  l.D = o; o += align_up(P * 4, 16);
+  l.pf_idx = o; o += align_up(P * 4, 16);
+  l.pvalid = o; o += align_up(P, 16);
+  l.pa_active = o; o += align_up(P, 16);
+  l.pang_active = o; o += align_up(P, 16);
+  l.lut_cost = o; o += 256 * 4;   // CostCritic repulsive term per 8-bit cost
+  l.total = o;
+  return l;
+}
+
+SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
+                 uint32_t nsamp)
+{
+  SmpcLds L{};
+  uint32_t o = with_map ? align_up(window_bytes, 16) : 0;
+  // 256 entries + one all-zero entry (index 256: the lane pass primes its lookup pipeline with it)
+  L.off_lut = o; o += with_map ? (256 + 2) * sizeof(SmpcLut) : 0;
+  const uint32_t pf = align_up(std::max(P, 1u) * 4, 16);
+  L.off_px = o; o += pf;
+  L.off_py = o; o += pf;
+  L.off_pyaw = o; o += pf;
+  L.off_D = o; o += align_up((std::max(P, 1u) + 2) * 4, 16);   // + a sentinel on either side (lane pass)
+  L.off_valid = o; o += align_up(std::max(P, 1u), 16);
+  L.off_scr = o;
+  // lanes per parked rollout: sample slots 0..nsamp fit one segment of 16/32/64 lanes;
+  // rollouts per flush: as many segments as a wave has, capped so that the parked
+  // controls stay <= 3 KiB per wave
+  const uint32_t R = T <= 64 ? 1 : (T <= 128 ? 2 : 4);
+  L.seg_shift = nsamp + 1 <= 16 ? 4 : (nsamp + 1 <= 32 ? 5 : 6);
+  L.group = std::max(1u, std::min(64u >> L.seg_shift, 4u / R));
+  // per wave: [sample points 3x64][endpoint ring 2x64][parked controls group x 3T]; the head is
+  // re-used for the block combine [4+3T]
+  L.scr_pts = 0;
+  L.scr_ring = 3 * 64;
+  L.scr_c = L.scr_ring + 2 * 64;
+  L.scr_stride = align_up(std::max(L.scr_c + L.group * 3 * T, 4 + 3 * T), 4);
+  o += nwave * L.scr_stride * 4;
+  L.total = o;
+  return L;
+}
+
+// LDS layout of the lane-per-rollout pass: window + the NO_INFORMATION byte + one scratch byte
+// per lane (cell_byte_exact), LUT, path, per wave the parked wz [64][68] + weights [64]
+SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T)
+{
+  const uint32_t lblock = smpc_lane_block();
+  SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
+                        window_bytes != 0, 0);
+  Lt.off_pts4 = Lt.off_scr;
+  Lt.off_scr += align_up(std::max(P, 1u) * 16, 16);
+  Lt.scr_stride = align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);
+  Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
+  return Lt;
+}
+
+// distanceToObstacle (obstacles_critic.cpp:99-112) for an 8-bit cost, point mode
+static float distance_to_obstacle(const HostCostmap& m, float cost, bool using_footprint = false)
+{
+  const float scale_factor = m.cost_scaling_factor;
+  const float min_radius = m.inscribed_radius;
+  float d = static_cast<float>(
+    (static_cast<double>(scale_factor * min_radius) - std::log(static_cast<double>(cost)) +
+    std::log(static_cast<double>(253.0f))) / static_cast<double>(scale_factor));
+  if (!using_footprint) d -= min_radius;   // obstacles_critic.cpp:106-108
+  return d;
+}
+
+// consider_fp: the critic's consider_footprint collision rule; using_fp: the cost came from the
+// footprint (no inscribed-radius offset, obstacles_critic.cpp:106-108)
+static void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut, bool consider_fp = false,
+               bool using_fp = false)
+{
+  const auto& m = c->map;
+  const auto& p = c->critics.obstacles;
+  for (int v = 0; v < 256; ++v) {
+    lut[v].crit = 0.f;
+    lut[v].rep = 0.f;
+    // inCollision (obstacles_critic.cpp:185-201), consider_footprint = false
+    if (v == SMPC_COST_LETHAL || (v == SMPC_COST_INSCRIBED && !consider_fp) ||
+      (v == SMPC_COST_NO_INFORMATION && !m.track_unknown))
+    {
+      lut[v].crit = -1.0f;                                   // :152 collision marker
+      continue;
+    }
+    if (v < 1) continue;                                     // :150 free space
+    if (m.inflation_radius == 0.0f || m.cost_scaling_factor == 0.0f) continue;  // :155
+    const float d = distance_to_obstacle(m, static_cast<float>(v), using_fp);
+    if (d < p.collision_margin_distance) {
+      lut[v].crit = p.collision_margin_distance - d;         // :165
+    } else if (!near_goal) {
+      lut[v].rep = m.inflation_radius - d;                   // :167
+    }
+  }
+}
+
+int check_tick(smpc_ctx* c, const smpc_tick_in* in)
+{
+  if (!c || !in) return SMPC_ERR_INVALID;
+  if (!c->have_noise) return fail(c, SMPC_ERR_STATE, "no noise: call smpc_set_noise or smpc_seed");
+  if (in->path_len > 0 && (!in->path_x || !in->path_y || !in->path_yaw))
+    return fail(c, SMPC_ERR_INVALID, "path arrays missing");
+  if (in->path_len > SMPC_MAX_PATH)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "path longer than SMPC_MAX_PATH (1024) points");
+  if (!c->map.set && (c->critics.obstacles.enabled || c->critics.cost.enabled || !in->path_pts_valid))
+    return fail(c, SMPC_ERR_STATE, "no costmap: call smpc_set_costmap");
+  if (((c->critics.obstacles.enabled && c->critics.obstacles.consider_footprint) ||
+    (c->critics.cost.enabled && c->critics.cost.consider_footprint)) && c->fp_x.empty())
+    return fail(c, SMPC_ERR_STATE, "consider_footprint=true needs a footprint: call smpc_set_footprint");
+  // with a footprint the two collision critics no longer see the same set of colliding
+  // rollouts, and the tuple carries one non-colliding count
+  if (c->critics.obstacles.enabled && c->critics.cost.enabled &&
+    (c->critics.obstacles.consider_footprint || c->critics.cost.consider_footprint))
+    return fail(c, SMPC_ERR_UNSUPPORTED,
+                "consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
+  return SMPC_OK;
+}
+
+// Everything the reference's critics decide once per tick on the host, plus the
+// upload of the tick block.  Leaves c->dev ready for the launches.
+int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
+{
+  int rc = check_tick(c, in);
+  if (rc != SMPC_OK) return rc;
+  if (!u_in) return fail(c, SMPC_ERR_INVALID, "control sequence missing");
+  const uint32_t T = c->cfg.time_steps, B = c->cfg.batch_size, P = in->path_len;
+  const auto& cr = c->critics;
+  HIPCK(c, hipSetDevice(c->device));
+
+  const TickLayout tl = tick_layout(T, std::max(P, 1u));
+  if (tl.total > c->tick_cap) return fail(c, SMPC_ERR_INVALID, "tick block overflow");
+  uint8_t* h = c->h_tick;
+  memcpy(h + tl.u, u_in, 3 * T * sizeof(float));
+  if (!c->holonomic) memset(h + tl.u + T * sizeof(float), 0, T * sizeof(float));
+  float* px = reinterpret_cast<float*>(h + tl.px);
+  float* py = reinterpret_cast<float*>(h + tl.py);
+  float* pyaw = reinterpret_cast<float*>(h + tl.pyaw);
+  float* D = reinterpret_cast<float*>(h + tl.D);
+  uint32_t* pf_idx = reinterpret_cast<uint32_t*>(h + tl.pf_idx);
+  uint8_t* pvalid = h + tl.pvalid;
+  uint8_t* pa_active = h + tl.pa_active;
+  if (P) {
+    memcpy(px, in->path_x, P * 4);
+    memcpy(py, in->path_y, P * 4);
+    memcpy(pyaw, in->path_yaw, P * 4);
+  }
+
+  // ---- host-side gates: one withinPositionGoalTolerance per critic
+  const double rx = in->pose_x, ry = in->pose_y, gx = in->goal_x, gy = in->goal_y;
+  uint32_t gates = 0;
+  if (cr.obstacles.enabled) gates |= SD_OBSTACLES;
+  if (cr.path_align.enabled && !within_tol(cr.path_align.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_ALIGN;                                   // path_align_critic.cpp:49-54
+  if (cr.path_follow.enabled && P >= 2 &&
+    !within_tol(cr.path_follow.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_FOLLOW;                                  // path_follow_critic.cpp:37-42
+  if (cr.goal_angle.enabled && P >= 1 &&
+    within_tol(cr.goal_angle.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_GOAL_ANGLE;                                   // goal_angle_critic.cpp:38-43
+  if (cr.prefer_forward.enabled &&
+    !within_tol(cr.prefer_forward.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PREFER_FORWARD;                               // prefer_forward_critic.cpp:36-41
+  // the other registered critics (general pass only)
+  if (cr.constraint.enabled) gates |= SD_CONSTRAINT;
+  if (cr.cost.enabled) gates |= SD_COST;
+  if (cr.obstacles.enabled && cr.obstacles.consider_footprint) gates |= SD_FP_OBSTACLES;
+  if (cr.cost.enabled && cr.cost.consider_footprint) gates |= SD_FP_COST;
+  if (cr.goal.enabled && within_tol(cr.goal.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_GOAL;                                         // goal_critic.cpp:38-42
+  if (cr.twirling.enabled) {
+    // utils::withinPositionGoalTolerance(goal_checker, ...) (tools/utils.hpp:201-224)
+    bool within = false;
+    if (in->goal_checker_xy_tolerance >= 0.0f) {
+      const double tol = static_cast<double>(in->goal_checker_xy_tolerance);
+      const double dx = rx - gx, dy = ry - gy;
+      within = dx * dx + dy * dy < tol * tol;
+    }
+    if (!within) gates |= SD_TWIRLING;                        // twirling_critic.cpp:33-37
+  }
+  if (cr.path_angle.enabled && P >= 1 &&
+    !within_tol(cr.path_angle.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_ANGLE;                                   // path_angle_critic.cpp:60-69
+  if (cr.velocity_deadband.enabled) gates |= SD_DEADBAND;
+  if (P == 0) gates &= ~(SD_PATH_ALIGN | SD_PATH_FOLLOW);
+  uint32_t nsamp = 0;
+  const uint32_t step = cr.path_align.trajectory_point_step;
+  if (gates & SD_PATH_ALIGN) {
+    nsamp = step > 0 ? (T - 1) / step : 0;
+    if (nsamp > 63)
+      return fail(c, SMPC_ERR_UNSUPPORTED,
+                  "PathAlign: more than 63 samples per trajectory (time_steps / trajectory_point_step)");
+    if (nsamp == 0) gates &= ~SD_PATH_ALIGN;  // no samples: cost 0 for every rollout
+    if (cr.path_align.use_path_orientations) gates |= SD_USE_PATH_YAW;
+  }
+  if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW | SD_PATH_ANGLE)) gates |= SD_NEED_FURTHEST;
+  if (c->map.track_unknown) gates |= SD_TRACK_UNKNOWN;
+  if (c->cfg.flags & SMPC_FLAG_STORE_TRAJECTORIES) gates |= SD_STORE_TRAJ;
+
+  // ---- path validity (utils::findPathCosts, tools/utils.hpp:361-395) ----------
+  const uint32_t nseg = P > 0 ? P - 1 : 0;
+  if (in->path_pts_valid) {
+    memcpy(pvalid, in->path_pts_valid, nseg);
+  } else if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW)) {
+    for (uint32_t i = 0; i < nseg; ++i) {
+      unsigned mx, my;
+      uint8_t v = 1;
+      if (!world_to_map(c->map, px[i], py[i], mx, my)) {
+        v = 0;
+      } else {
+        const uint8_t cost = c->map.cells[static_cast<size_t>(my) * c->map.W + mx];
+        if (cost == SMPC_COST_LETHAL || cost == SMPC_COST_INSCRIBED) v = 0;
+        else if (cost == SMPC_COST_NO_INFORMATION) v = c->map.track_unknown ? 1 : 0;
+      }
+      pvalid[i] = v;
+    }
+  } else {
+    memset(pvalid, 0, std::max(nseg, 1u));
+  }
+
+  // ---- PathAlign: cumulative path lengths (path_align_critic.cpp:82-90) --------
+  if (nseg) {
+    D[0] = 0.0f;
+    for (uint32_t i = 1; i < nseg; ++i) {
+      const float dx = px[i] - px[i - 1];
+      const float dy = py[i] - py[i - 1];
+      D[i] = D[i - 1] + sqrtf(dx * dx + dy * dy);
+    }
+  }
+
+  // ---- per-candidate-furthest-point tables -------------------------------------
+  const float yaw0 = in->pose_yaw;
+  const float cos0 = cosf(yaw0), sin0 = sinf(yaw0);
+  const float svx = static_cast<float>(in->speed_vx);
+  // state.vy[:,0] = speed.linear.y only if holonomic (optimizer.cpp:264-266)
+  const float svy = c->holonomic ? static_cast<float>(in->speed_vy) : 0.f;
+  const float swz = static_cast<float>(in->speed_wz);
+  const float dt = c->cfg.model_dt;
+  // trajectories(0,0): first rollout point, identical for every rollout because
+  // v[:,0] is the measured speed (optimizer.cpp:258-267,331-342)
+  const float dx0 = svx * cos0 - svy * sin0;
+  const float dy0 = svx * sin0 + svy * cos0;
+  const float x00 = static_cast<float>(in->pose_x + static_cast<double>(dx0 * dt));
+  const float y00 = static_cast<float>(in->pose_y + static_cast<double>(dy0 * dt));
+  uint32_t cost_t0 = SMPC_COST_NO_INFORMATION;   // costAtPose of that point (obstacles_critic.cpp:203-212)
+  if (c->map.set) {
+    unsigned mx, my;
+    if (world_to_map(c->map, x00, y00, mx, my))
+      cost_t0 = c->map.cells[static_cast<size_t>(my) * c->map.W + mx];
+  }
+  if (gates & SD_PATH_ALIGN) {
+    // utils::findPathTrajectoryInitialPoint (tools/utils.hpp:327-344)
+    size_t init = 0;
+    float best = std::numeric_limits<float>::max();
+    for (uint32_t j = 0; j < P; ++j) {
+      const float ddx = px[j] - x00, ddy = py[j] - y00;
+      const float d = ddx * ddx + ddy * ddy;
+      if (d < best) {
+        best = d;
+        init = j;
+      }
+    }
+    // :64-74 occupancy of the path between the initial and the furthest point.  The
+    // reference walks i = init..S-1 with a running count of invalid points and stops at the
+    // first i where count / range > ratio and count > 2; the count only grows and range is
+    // fixed per S, so that happens iff it holds for the final count: prefix sums, O(P).
+    std::vector<uint32_t> inval(P + 1, 0);
+    for (uint32_t i = 0; i < P; ++i) inval[i + 1] = inval[i] + ((i + 1 < P && !pvalid[i]) ? 1u : 0u);
+    for (uint32_t S = 0; S < P; ++S) {
+      bool on = S >= cr.path_align.offset_from_furthest;     // path_align_critic.cpp:58-61
+      if (on && S > init) {
+        const unsigned int invalid_ctr = inval[S] - inval[init];
+        const float range = static_cast<float>(static_cast<size_t>(S) - init);
+        if (static_cast<float>(invalid_ctr) / range > cr.path_align.max_path_occupancy_ratio &&
+          invalid_ctr > 2)
+        {
+          on = false;
+        }
+      }
+      pa_active[S] = on ? 1 : 0;
+    }
+  } else {
+    memset(pa_active, 0, std::max(P, 1u));
+  }
+  if (gates & SD_PATH_FOLLOW) {
+    // path_follow_critic.cpp:46-57
+    const size_t path_size = P - 1;
+    for (uint32_t S = 0; S < P; ++S) {
+      size_t idx = std::min(static_cast<size_t>(S) + cr.path_follow.offset_from_furthest, path_size);
+      bool valid = false;
+      while (!valid && idx < path_size - 1) {
+        valid = pvalid[idx];
+        if (!valid) idx++;
+      }
+      pf_idx[S] = static_cast<uint32_t>(idx);
+    }
+  } else {
+    memset(pf_idx, 0, std::max(P, 1u) * 4);
+  }
+
+  uint8_t* pang_active = h + tl.pang_active;
+  bool pang_correct = false;
+  if (gates & SD_PATH_ANGLE) {
+    // path_angle_critic.cpp:24-31,52-54: reversing / forward preference
+    bool reversing_allowed = true;
+    if (std::fabs(cr.path_angle.vx_min) < 1e-6) reversing_allowed = false;
+    else if (cr.path_angle.vx_min < 0.0f) reversing_allowed = true;
+    bool forward_preference = cr.path_angle.forward_preference != 0;
+    if (!reversing_allowed) forward_preference = true;
+    pang_correct = reversing_allowed && !forward_preference;
+    for (uint32_t S = 0; S < P; ++S) {
+      // :73-83 utils::posePointAngle (tools/utils.hpp:417-434) against the offset point
+      const size_t idx = std::min(static_cast<size_t>(S) + cr.path_angle.offset_from_furthest,
+                                  static_cast<size_t>(P) - 1);
+      const float pose_x = static_cast<float>(rx), pose_y = static_cast<float>(ry);
+      const double point_x = px[idx], point_y = py[idx];
+      const float yaw = atan2f(static_cast<float>(point_y - static_cast<double>(pose_y)),
+                               static_cast<float>(point_x - static_cast<double>(pose_x)));
+      auto norm = [](double a) {
+        const double theta = std::fmod(a + M_PI, 2.0 * M_PI);
+        return theta <= 0.0 ? theta + M_PI : theta - M_PI;
+      };
+      const double pyaw0 = static_cast<double>(in->pose_yaw);
+      float ang = static_cast<float>(std::fabs(norm(pyaw0 - static_cast<double>(yaw))));
+      if (!forward_preference) {
+        const double b = std::fabs(norm(norm(pyaw0 + M_PI) - static_cast<double>(yaw)));
+        ang = static_cast<float>(std::min(std::fabs(norm(pyaw0 - static_cast<double>(yaw))), b));
+      }
+      pang_active[S] = ang < cr.path_angle.max_angle_to_furthest ? 0 : 1;
+    }
+  } else {
+    memset(pang_active, 0, std::max(P, 1u));
+  }
+  float* lut_cost = reinterpret_cast<float*>(h + tl.lut_cost);
+  if (gates & SD_COST) {
+    // cost_critic.cpp:120-124,141-155 per 8-bit cost (collisions are marked in the shared LUT)
+    const bool near_goal_c = within_tol(cr.cost.near_goal_distance, rx, ry, gx, gy);
+    for (int v = 0; v < 256; ++v) {
+      float t = 0.0f;
+      if (v >= 1) {
+        if (static_cast<float>(v) >= static_cast<float>(SMPC_COST_INSCRIBED)) t = cr.cost.critical_cost;
+        else if (!near_goal_c) t = static_cast<float>(v);
+      }
+      lut_cost[v] = t;
+    }
+  } else {
+    memset(lut_cost, 0, 256 * 4);
+  }
+
+  // ---- Obstacles LUT: rebuilt and uploaded only when its inputs changed -----------
+  if (gates & (SD_OBSTACLES | SD_COST)) {
+    const bool near_goal = within_tol(cr.obstacles.near_goal_distance, rx, ry, gx, gy);  // :124-127
+    const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 2) ^ (near_goal ? 1u : 0u) ^
+      ((gates & (SD_FP_OBSTACLES | SD_FP_COST)) ? 2u : 0u);
+    if (!c->lut_valid || key != c->lut_key) {
+      build_lut(c, near_goal, c->h_lut);
+      HIPCK(c, hipMemcpyAsync(c->d_lut, c->h_lut, 256 * sizeof(SmpcLut), hipMemcpyHostToDevice,
+                              c->stream));
+      if (gates & (SD_FP_OBSTACLES | SD_FP_COST)) {
+        build_lut(c, near_goal, c->h_lut_fp, true, false);
+        build_lut(c, near_goal, c->h_lut_fp + 256, true, true);
+        HIPCK(c, hipMemcpyAsync(c->d_lut_fp, c->h_lut_fp, 512 * sizeof(SmpcLut), hipMemcpyHostToDevice,
+                                c->stream));
+      }
+      c->lut_key = key;
+      c->lut_valid = true;
+    }
+  }
+
+  {
+    const int rc_map = wait_map_upload(c);
+    if (rc_map != SMPC_OK) return rc_map;
+  }
+  if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev0, c->stream));
+  if (!c->defer_upload)
+    HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
+
+  // ---- kernel parameter block ------------------------------------------------------
+  SmpcDev& d = c->dev;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.T = T; d.P = P; d.nsamp = nsamp; d.step = step;
+  d.x0 = in->pose_x; d.y0 = in->pose_y;
+  d.yaw0 = yaw0; d.cos0 = cos0; d.sin0 = sin0;
+  d.svx = svx; d.svy = svy; d.swz = swz; d.dt = dt;
+  d.nvx = c->d_nvx; d.nvy = c->d_nvy; d.nwz = c->d_nwz;
+  d.tvx = c->d_tvx; d.tvy = c->d_tvy; d.twz = c->d_twz;
+  d.u = reinterpret_cast<const float*>(c->d_tick + tl.u);
+  d.traj_x = c->d_traj[0]; d.traj_y = c->d_traj[1]; d.traj_yaw = c->d_traj[2];
+  d.map = c->d_map; d.W = c->map.W; d.H = c->map.H;
+  d.ox = c->map.ox; d.oy = c->map.oy; d.res = c->map.res;
+  d.cost_t0 = cost_t0;
+  d.x00f = x00; d.y00f = y00;
+  {
+    // fast cell index: float quotient + guard band (see cost_at in smpc_kernels.hip)
+    const double rinv = 1.0 / c->map.res;
+    d.oxf = static_cast<float>(c->map.ox);
+    d.oyf = static_cast<float>(c->map.oy);
+    d.rinvf = static_cast<float>(rinv);
+    const double e_o = std::max(std::fabs(c->map.ox - static_cast<double>(d.oxf)),
+                                std::fabs(c->map.oy - static_cast<double>(d.oyf)));
+    const double qmax = static_cast<double>(std::max(c->map.W, c->map.H)) + 2.0;
+    const double eps = 2.0 * (e_o * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
+    d.cell_eps = static_cast<float>(std::min(eps, 0.5));
+  }
+  d.lut = c->d_lut;
+  d.px = reinterpret_cast<const float*>(c->d_tick + tl.px);
+  d.py = reinterpret_cast<const float*>(c->d_tick + tl.py);
+  d.pyaw = reinterpret_cast<const float*>(c->d_tick + tl.pyaw);
+  d.D = reinterpret_cast<const float*>(c->d_tick + tl.D);
+  d.pvalid = c->d_tick + tl.pvalid;
+  d.pa_active = c->d_tick + tl.pa_active;
+  d.pf_idx = reinterpret_cast<const uint32_t*>(c->d_tick + tl.pf_idx);
+  d.obs_critical_w = cr.obstacles.critical_weight;
+  d.obs_repulsion_w = cr.obstacles.repulsion_weight;
+  d.obs_collision_cost = cr.obstacles.collision_cost;
+  d.obs_rep_over_T = cr.obstacles.repulsion_weight / static_cast<float>(T);
+  d.obs_power = cr.obstacles.cost_power;
+  d.pa_weight = cr.path_align.cost_weight; d.pa_power = cr.path_align.cost_power;
+  d.pf_weight = cr.path_follow.cost_weight; d.pf_power = cr.path_follow.cost_power;
+  d.ga_weight = cr.goal_angle.cost_weight; d.ga_power = cr.goal_angle.cost_power;
+  d.ga_goal_yaw = P ? pyaw[P - 1] : 0.f;
+  d.pfw_weight = cr.prefer_forward.cost_weight; d.pfw_power = cr.prefer_forward.cost_power;
+  d.con_weight = cr.constraint.cost_weight; d.con_power = cr.constraint.cost_power;
+  {
+    // ConstraintCritic::initialize (constraint_critic.cpp:36-38)
+    const float min_sgn = cr.constraint.vx_min > 0.0f ? 1.0f : -1.0f;
+    d.con_max_vel = sqrtf(cr.constraint.vx_max * cr.constraint.vx_max + cr.constraint.vy_max * cr.constraint.vy_max);
+    d.con_min_vel = min_sgn * sqrtf(cr.constraint.vx_min * cr.constraint.vx_min + cr.constraint.vy_max * cr.constraint.vy_max);
+    d.con_acker_r = c->acker_r;
+  }
+  d.lut_cost = reinterpret_cast<const float*>(c->d_tick + tl.lut_cost);
+  d.cost_w254 = cr.cost.cost_weight / 254.0f;   // cost_critic.cpp:34
+  d.cost_collision_cost = cr.cost.collision_cost; d.cost_power = cr.cost.cost_power;
+  d.goal_x = in->goal_x; d.goal_y = in->goal_y;
+  d.goal_weight = cr.goal.cost_weight; d.goal_power = cr.goal.cost_power;
+  d.tw_weight = cr.twirling.cost_weight; d.tw_power = cr.twirling.cost_power;
+  d.pang_active = c->d_tick + tl.pang_active;
+  d.pang_weight = cr.path_angle.cost_weight; d.pang_power = cr.path_angle.cost_power;
+  d.pang_offset = cr.path_angle.offset_from_furthest; d.pang_correct = pang_correct ? 1 : 0;
+  d.db_vx = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[0]));
+  // no vy term for a non-holonomic model (velocity_deadband_critic.cpp:78-97); with
+  // state.vy = 0 a zero deadband contributes max(0 - 0, 0) = 0
+  d.db_vy = c->holonomic ? std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[1])) : 0.0;
+  d.db_wz = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[2]));
+  d.db_weight = cr.velocity_deadband.cost_weight; d.db_power = cr.velocity_deadband.cost_power;
+  d.lut_fp = c->d_lut_fp;
+  d.fp_n = static_cast<uint32_t>(c->fp_x.size());
+  for (uint32_t i = 0; i < d.fp_n; ++i) {
+    d.fp_x[i] = c->fp_x[i];
+    d.fp_y[i] = c->fp_y[i];
+  }
+  d.fp_pic = 0.0f;
+  if (gates & (SD_FP_OBSTACLES | SD_FP_COST)) {
+    // {Obstacles,Cost}Critic::findCircumscribedCost with InflationLayer::computeCost
+    // (nav2_costmap_2d, Humble): the cost at the circumscribed radius, -1 without a layer
+    double result = -1.0;
+    if (c->fp_layer_scale >= 0.0) {
+      const double distance = c->fp_circumscribed_radius / c->map.res;
+      unsigned char cost = 0;
+      if (distance == 0) {
+        cost = SMPC_COST_LETHAL;
+      } else if (distance * c->map.res <= static_cast<double>(c->map.inscribed_radius)) {
+        cost = SMPC_COST_INSCRIBED;
+      } else {
+        const double factor = std::exp(-1.0 * c->fp_layer_scale *
+                                       (distance * c->map.res - static_cast<double>(c->map.inscribed_radius)));
+        cost = static_cast<unsigned char>((SMPC_COST_INSCRIBED - 1) * factor);
+      }
+      result = cost;
+    }
+    d.fp_pic = static_cast<float>(result);
+  }
+  d.g_vx = c->cfg.gamma / powf(c->cfg.vx_std, 2);
+  d.g_vy = c->holonomic ? c->cfg.gamma / powf(c->cfg.vy_std, 2) : 0.f;   // optimizer.cpp:374-380
+  d.g_wz = c->cfg.gamma / powf(c->cfg.wz_std, 2);
+  d.neg_inv_temp = -1 / c->cfg.temperature;
+  d.k2 = d.neg_inv_temp * 1.4426950408889634f;
+  d.timeline = c->d_timeline;
+  d.partials = c->d_partials;
+  d.furthest_out = reinterpret_cast<uint32_t*>(c->d_furthest);
+
+  // ---- costmap window staged in LDS, centred on the robot ---------------------------
+  uint32_t window_bytes = 0;
+  if (c->map.set && (gates & (SD_OBSTACLES | SD_COST))) {
+    uint32_t side = 4;
+    while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 96 cells
+    const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
+    long cx = static_cast<long>((in->pose_x - c->map.ox) / c->map.res);
+    long cy = static_cast<long>((in->pose_y - c->map.oy) / c->map.res);
+    long wx0 = cx - ww / 2, wy0 = cy - wh / 2;
+    wx0 = std::max(0L, std::min(wx0, static_cast<long>(c->map.W) - static_cast<long>(ww)));
+    wy0 = std::max(0L, std::min(wy0, static_cast<long>(c->map.H) - static_cast<long>(wh)));
+    wx0 &= ~3L;
+    d.win_x0 = static_cast<int32_t>(wx0); d.win_y0 = static_cast<int32_t>(wy0);
+    d.win_w = static_cast<int32_t>(ww); d.win_h = static_cast<int32_t>(wh);
+    window_bytes = ww * wh;
+  }
+  c->lds = make_lds(window_bytes, P, T, (pass_block(c->R) / 64), window_bytes != 0, nsamp);
+  if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
+
+  // persistent grid: as many blocks as stay resident, never more than the work
+  const uint32_t waves_per_block = (pass_block(c->R) / 64);
+  int mode_now = c->score_mode_for(cr);
+  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | SD_EXTRA_CRITICS)) mode_now = 2;   // lean kernels lack these
+  if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
+    int nb = 0;
+    if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), pass_block(c->R), c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
+    c->occ_blocks = static_cast<uint32_t>(nb);
+    c->occ_lds = c->lds.total;
+    c->occ_mode = mode_now;
+  }
+  uint32_t per_cu = std::min(c->occ_blocks, 32u / waves_per_block);
+  if (const char* e = getenv("SMPC_MAX_BLOCKS_PER_CU")) {   // tuning knob
+    const uint32_t lim = static_cast<uint32_t>(atoi(e));
+    if (lim >= 1) per_cu = std::min(per_cu, lim);
+  }
+  uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
+                           static_cast<uint32_t>(c->num_cu) * per_cu);
+  c->grid = std::max(1u, std::min(grid, kMaxGrid));
+  c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
+  // the lane pass samples PathAlign's trajectory points at the first step of every quad:
+  // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
+  if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
+  if (c->lane_now) {
+    const SmpcLds Lt = lane_lds(window_bytes, P, T);
+    c->lane_window_bytes = window_bytes;
+    c->lds_tpr = Lt;
+    if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
+  }
+  if (c->lane_now) {
+    const uint32_t lblock = smpc_lane_block();
+    const SmpcLds& Lt = c->lds_tpr;
+    if (c->occ_tpr_lds != Lt.total) {
+      int nb = 0;
+      if (smpc_lane_occupancy(T == 64, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
+      c->occ_tpr_blocks = static_cast<uint32_t>(nb);
+      c->occ_tpr_lds = Lt.total;
+    }
+    const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
+    uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
+    c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
+    // window-relative float cell index and its guard band (cost_at_lane)
+    const double rinv = 1.0 / c->map.res;
+    const double wx = c->map.ox + static_cast<double>(d.win_x0) * c->map.res;
+    const double wy = c->map.oy + static_cast<double>(d.win_y0) * c->map.res;
+    d.wxf = static_cast<float>(wx);
+    d.wyf = static_cast<float>(wy);
+    const double e_o = std::max(std::fabs(wx - static_cast<double>(d.wxf)),
+                                std::fabs(wy - static_cast<double>(d.wyf)));
+    // the reference divides (x - origin) by the resolution; the window corner is
+    // origin + win0 * res in double: one more rounding of that product and sum
+    const double e_c = 2.3e-16 * (std::fabs(wx) + std::fabs(wy) + 1.0);
+    const double qmax = static_cast<double>(std::max(d.win_w, d.win_h)) + 2.0;
+    const double eps = 2.0 * ((e_o + e_c) * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
+    d.cell_eps_w = static_cast<float>(std::min(eps, 0.5));
+  }
+
+  c->gate_flags = gates;
+  c->score_mode = mode_now;
+  c->fail_in = in->fail_flag_in != 0;
+  c->P = P;
+  c->tick_ready = true;
+  return SMPC_OK;
+}
+
+}  // namespace smpc_impl
