@@ -133,34 +133,13 @@ int check_tick(smpc_ctx* c, const smpc_tick_in* in)
 
 // Everything the reference's critics decide once per tick on the host, plus the
 // upload of the tick block.  Leaves c->dev ready for the launches.
-int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
+// Which critics score this tick: membership in the critics list, and for the gated ones the
+// reference's withinPositionGoalTolerance test at the top of score().  Also the
+// number of PathAlign samples per trajectory.
+static int tick_gates(smpc_ctx* c, const smpc_tick_in* in, uint32_t& gates_out, uint32_t& nsamp_out)
 {
-  int rc = check_tick(c, in);
-  if (rc != SMPC_OK) return rc;
-  if (!u_in) return fail(c, SMPC_ERR_INVALID, "control sequence missing");
-  const uint32_t T = c->cfg.time_steps, B = c->cfg.batch_size, P = in->path_len;
+  const uint32_t T = c->cfg.time_steps, P = in->path_len;
   const auto& cr = c->critics;
-  HIPCK(c, hipSetDevice(c->device));
-
-  const TickLayout tl = tick_layout(T, std::max(P, 1u));
-  if (tl.total > c->tick_cap) return fail(c, SMPC_ERR_INVALID, "tick block overflow");
-  uint8_t* h = c->h_tick;
-  memcpy(h + tl.u, u_in, 3 * T * sizeof(float));
-  if (!c->holonomic) memset(h + tl.u + T * sizeof(float), 0, T * sizeof(float));
-  float* px = reinterpret_cast<float*>(h + tl.px);
-  float* py = reinterpret_cast<float*>(h + tl.py);
-  float* pyaw = reinterpret_cast<float*>(h + tl.pyaw);
-  float* D = reinterpret_cast<float*>(h + tl.D);
-  uint32_t* pf_idx = reinterpret_cast<uint32_t*>(h + tl.pf_idx);
-  uint8_t* pvalid = h + tl.pvalid;
-  uint8_t* pa_active = h + tl.pa_active;
-  if (P) {
-    memcpy(px, in->path_x, P * 4);
-    memcpy(py, in->path_y, P * 4);
-    memcpy(pyaw, in->path_yaw, P * 4);
-  }
-
-  // ---- host-side gates: one withinPositionGoalTolerance per critic
   const double rx = in->pose_x, ry = in->pose_y, gx = in->goal_x, gy = in->goal_y;
   uint32_t gates = 0;
   if (cr.obstacles.enabled) gates |= SD_OBSTACLES;
@@ -211,6 +190,17 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   if (c->map.track_unknown) gates |= SD_TRACK_UNKNOWN;
   if (c->cfg.flags & SMPC_FLAG_STORE_TRAJECTORIES) gates |= SD_STORE_TRAJ;
 
+  gates_out = gates;
+  nsamp_out = nsamp;
+  return SMPC_OK;
+}
+
+// Path validity (utils::findPathCosts) and PathAlign's cumulative path lengths, into the tick
+// block: pvalid[P-1], D[P-1].
+static void path_tables(const smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, const float* px,
+                        const float* py, uint8_t* pvalid, float* D)
+{
+  const uint32_t P = in->path_len;
   // ---- path validity (utils::findPathCosts, tools/utils.hpp:361-395) ----------
   const uint32_t nseg = P > 0 ? P - 1 : 0;
   if (in->path_pts_valid) {
@@ -241,6 +231,130 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
       D[i] = D[i - 1] + sqrtf(dx * dx + dy * dy);
     }
   }
+
+}
+
+// Launch geometry of the tick: the costmap window staged in LDS (centred on the robot), the LDS
+// carve-up and persistent grid of the wave-per-rollout pass, which scoring mode the enabled
+// critics need, and whether — and how — the lane-per-rollout pass takes the tick.
+static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint32_t nsamp, int& mode_out)
+{
+  const uint32_t T = c->cfg.time_steps, B = c->cfg.batch_size, P = in->path_len;
+  const auto& cr = c->critics;
+  const uint32_t step = cr.path_align.trajectory_point_step;
+  SmpcDev& d = c->dev;
+  uint32_t window_bytes = 0;
+  if (c->map.set && (gates & (SD_OBSTACLES | SD_COST))) {
+    uint32_t side = 4;
+    while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 96 cells
+    const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
+    long cx = static_cast<long>((in->pose_x - c->map.ox) / c->map.res);
+    long cy = static_cast<long>((in->pose_y - c->map.oy) / c->map.res);
+    long wx0 = cx - ww / 2, wy0 = cy - wh / 2;
+    wx0 = std::max(0L, std::min(wx0, static_cast<long>(c->map.W) - static_cast<long>(ww)));
+    wy0 = std::max(0L, std::min(wy0, static_cast<long>(c->map.H) - static_cast<long>(wh)));
+    wx0 &= ~3L;
+    d.win_x0 = static_cast<int32_t>(wx0); d.win_y0 = static_cast<int32_t>(wy0);
+    d.win_w = static_cast<int32_t>(ww); d.win_h = static_cast<int32_t>(wh);
+    window_bytes = ww * wh;
+  }
+  c->lds = make_lds(window_bytes, P, T, (pass_block(c->R) / 64), window_bytes != 0, nsamp);
+  if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
+
+  // persistent grid: as many blocks as stay resident, never more than the work
+  const uint32_t waves_per_block = (pass_block(c->R) / 64);
+  int mode_now = c->score_mode_for(cr);
+  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | SD_EXTRA_CRITICS)) mode_now = 2;   // lean kernels lack these
+  if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
+    int nb = 0;
+    if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), pass_block(c->R), c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
+    c->occ_blocks = static_cast<uint32_t>(nb);
+    c->occ_lds = c->lds.total;
+    c->occ_mode = mode_now;
+  }
+  uint32_t per_cu = std::min(c->occ_blocks, 32u / waves_per_block);
+  if (const char* e = getenv("SMPC_MAX_BLOCKS_PER_CU")) {   // tuning knob
+    const uint32_t lim = static_cast<uint32_t>(atoi(e));
+    if (lim >= 1) per_cu = std::min(per_cu, lim);
+  }
+  uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
+                           static_cast<uint32_t>(c->num_cu) * per_cu);
+  c->grid = std::max(1u, std::min(grid, kMaxGrid));
+  c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
+  // the lane pass samples PathAlign's trajectory points at the first step of every quad:
+  // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
+  if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
+  if (c->lane_now) {
+    const SmpcLds Lt = lane_lds(window_bytes, P, T);
+    c->lane_window_bytes = window_bytes;
+    c->lds_tpr = Lt;
+    if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
+  }
+  if (c->lane_now) {
+    const uint32_t lblock = smpc_lane_block();
+    const SmpcLds& Lt = c->lds_tpr;
+    if (c->occ_tpr_lds != Lt.total) {
+      int nb = 0;
+      if (smpc_lane_occupancy(T == 64, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
+      c->occ_tpr_blocks = static_cast<uint32_t>(nb);
+      c->occ_tpr_lds = Lt.total;
+    }
+    const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
+    uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
+    c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
+    // window-relative float cell index and its guard band (cost_at_lane)
+    const double rinv = 1.0 / c->map.res;
+    const double wx = c->map.ox + static_cast<double>(d.win_x0) * c->map.res;
+    const double wy = c->map.oy + static_cast<double>(d.win_y0) * c->map.res;
+    d.wxf = static_cast<float>(wx);
+    d.wyf = static_cast<float>(wy);
+    const double e_o = std::max(std::fabs(wx - static_cast<double>(d.wxf)),
+                                std::fabs(wy - static_cast<double>(d.wyf)));
+    // the reference divides (x - origin) by the resolution; the window corner is
+    // origin + win0 * res in double: one more rounding of that product and sum
+    const double e_c = 2.3e-16 * (std::fabs(wx) + std::fabs(wy) + 1.0);
+    const double qmax = static_cast<double>(std::max(d.win_w, d.win_h)) + 2.0;
+    const double eps = 2.0 * ((e_o + e_c) * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
+    d.cell_eps_w = static_cast<float>(std::min(eps, 0.5));
+  }
+
+  mode_out = mode_now;
+  return SMPC_OK;
+}
+
+int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
+{
+  int rc = check_tick(c, in);
+  if (rc != SMPC_OK) return rc;
+  if (!u_in) return fail(c, SMPC_ERR_INVALID, "control sequence missing");
+  const uint32_t T = c->cfg.time_steps, B = c->cfg.batch_size, P = in->path_len;
+  const auto& cr = c->critics;
+  HIPCK(c, hipSetDevice(c->device));
+
+  const TickLayout tl = tick_layout(T, std::max(P, 1u));
+  if (tl.total > c->tick_cap) return fail(c, SMPC_ERR_INVALID, "tick block overflow");
+  uint8_t* h = c->h_tick;
+  memcpy(h + tl.u, u_in, 3 * T * sizeof(float));
+  if (!c->holonomic) memset(h + tl.u + T * sizeof(float), 0, T * sizeof(float));
+  float* px = reinterpret_cast<float*>(h + tl.px);
+  float* py = reinterpret_cast<float*>(h + tl.py);
+  float* pyaw = reinterpret_cast<float*>(h + tl.pyaw);
+  float* D = reinterpret_cast<float*>(h + tl.D);
+  uint32_t* pf_idx = reinterpret_cast<uint32_t*>(h + tl.pf_idx);
+  uint8_t* pvalid = h + tl.pvalid;
+  uint8_t* pa_active = h + tl.pa_active;
+  if (P) {
+    memcpy(px, in->path_x, P * 4);
+    memcpy(py, in->path_y, P * 4);
+    memcpy(pyaw, in->path_yaw, P * 4);
+  }
+
+  uint32_t gates = 0, nsamp = 0;
+  rc = tick_gates(c, in, gates, nsamp);
+  if (rc != SMPC_OK) return rc;
+  const double rx = in->pose_x, ry = in->pose_y, gx = in->goal_x, gy = in->goal_y;
+  const uint32_t step = cr.path_align.trajectory_point_step;
+  path_tables(c, in, gates, px, py, pvalid, D);
 
   // ---- per-candidate-furthest-point tables -------------------------------------
   const float yaw0 = in->pose_yaw;
@@ -493,81 +607,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.partials = c->d_partials;
   d.furthest_out = reinterpret_cast<uint32_t*>(c->d_furthest);
 
-  // ---- costmap window staged in LDS, centred on the robot ---------------------------
-  uint32_t window_bytes = 0;
-  if (c->map.set && (gates & (SD_OBSTACLES | SD_COST))) {
-    uint32_t side = 4;
-    while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 96 cells
-    const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
-    long cx = static_cast<long>((in->pose_x - c->map.ox) / c->map.res);
-    long cy = static_cast<long>((in->pose_y - c->map.oy) / c->map.res);
-    long wx0 = cx - ww / 2, wy0 = cy - wh / 2;
-    wx0 = std::max(0L, std::min(wx0, static_cast<long>(c->map.W) - static_cast<long>(ww)));
-    wy0 = std::max(0L, std::min(wy0, static_cast<long>(c->map.H) - static_cast<long>(wh)));
-    wx0 &= ~3L;
-    d.win_x0 = static_cast<int32_t>(wx0); d.win_y0 = static_cast<int32_t>(wy0);
-    d.win_w = static_cast<int32_t>(ww); d.win_h = static_cast<int32_t>(wh);
-    window_bytes = ww * wh;
-  }
-  c->lds = make_lds(window_bytes, P, T, (pass_block(c->R) / 64), window_bytes != 0, nsamp);
-  if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
-
-  // persistent grid: as many blocks as stay resident, never more than the work
-  const uint32_t waves_per_block = (pass_block(c->R) / 64);
-  int mode_now = c->score_mode_for(cr);
-  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | SD_EXTRA_CRITICS)) mode_now = 2;   // lean kernels lack these
-  if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
-    int nb = 0;
-    if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), pass_block(c->R), c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
-    c->occ_blocks = static_cast<uint32_t>(nb);
-    c->occ_lds = c->lds.total;
-    c->occ_mode = mode_now;
-  }
-  uint32_t per_cu = std::min(c->occ_blocks, 32u / waves_per_block);
-  if (const char* e = getenv("SMPC_MAX_BLOCKS_PER_CU")) {   // tuning knob
-    const uint32_t lim = static_cast<uint32_t>(atoi(e));
-    if (lim >= 1) per_cu = std::min(per_cu, lim);
-  }
-  uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
-                           static_cast<uint32_t>(c->num_cu) * per_cu);
-  c->grid = std::max(1u, std::min(grid, kMaxGrid));
-  c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
-  // the lane pass samples PathAlign's trajectory points at the first step of every quad:
-  // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
-  if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
-  if (c->lane_now) {
-    const SmpcLds Lt = lane_lds(window_bytes, P, T);
-    c->lane_window_bytes = window_bytes;
-    c->lds_tpr = Lt;
-    if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
-  }
-  if (c->lane_now) {
-    const uint32_t lblock = smpc_lane_block();
-    const SmpcLds& Lt = c->lds_tpr;
-    if (c->occ_tpr_lds != Lt.total) {
-      int nb = 0;
-      if (smpc_lane_occupancy(T == 64, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
-      c->occ_tpr_blocks = static_cast<uint32_t>(nb);
-      c->occ_tpr_lds = Lt.total;
-    }
-    const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
-    uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
-    c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
-    // window-relative float cell index and its guard band (cost_at_lane)
-    const double rinv = 1.0 / c->map.res;
-    const double wx = c->map.ox + static_cast<double>(d.win_x0) * c->map.res;
-    const double wy = c->map.oy + static_cast<double>(d.win_y0) * c->map.res;
-    d.wxf = static_cast<float>(wx);
-    d.wyf = static_cast<float>(wy);
-    const double e_o = std::max(std::fabs(wx - static_cast<double>(d.wxf)),
-                                std::fabs(wy - static_cast<double>(d.wyf)));
-    // the reference divides (x - origin) by the resolution; the window corner is
-    // origin + win0 * res in double: one more rounding of that product and sum
-    const double e_c = 2.3e-16 * (std::fabs(wx) + std::fabs(wy) + 1.0);
-    const double qmax = static_cast<double>(std::max(d.win_w, d.win_h)) + 2.0;
-    const double eps = 2.0 * ((e_o + e_c) * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
-    d.cell_eps_w = static_cast<float>(std::min(eps, 0.5));
-  }
+  int mode_now = 0;
+  rc = plan_launch(c, in, gates, nsamp, mode_now);
+  if (rc != SMPC_OK) return rc;
 
   c->gate_flags = gates;
   c->score_mode = mode_now;
