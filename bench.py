@@ -255,6 +255,24 @@ def cpu_baseline(T, map_size, budget_s=12.0, B=65536, max_ticks=200):
     }
 
 
+def _exchange_agrees(g, scn, rank, HipShard, ShardedOptimizer, dist, torch):
+    """One tick through smpc_shard_tick (whichever exchange the ctx is set up for) and one through
+    the torch.distributed driver from the same state must give the same control sequence on every
+    rank; the verdict is shared, so that every rank keeps or drops the implementation together."""
+    agree = 0
+    try:
+        u_nat, o_nat = g.shard_tick(scn.tick, scn.u0, False)
+        u_ref, o_ref = ShardedOptimizer(HipShard(g), speculate=False).optimize(scn.tick, scn.u0)
+        agree = int(np.allclose(u_nat, u_ref, rtol=0, atol=1e-6) and
+                    o_nat.furthest_reached_path_point == o_ref.furthest_reached_path_point)
+    except Exception as e:
+        print(f"[bench] rank {rank}: exchange self-check raised: {e}", file=sys.stderr, flush=True)
+    g.set_stream(-1)      # SMPC_STREAM_OWN: back to the ctx's own stream
+    t = torch.tensor([agree], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,36 +312,33 @@ def main():
 
     exchange_impl = "none"
     if world > 1 or force_dist:
-        from mpcholonavigation_amd.sharded import HipShard, NativeShardedOptimizer, ShardedOptimizer
+        from mpcholonavigation_amd.sharded import (HipShard, MailboxShardedOptimizer, NativeShardedOptimizer,
+                                                   ShardedOptimizer)
         so = None
-        if os.environ.get("SMPC_BENCH_TORCH_EXCHANGE") != "1":
+        # SMPC_BENCH_EXCHANGE = mailbox | rccl | torch picks the first implementation tried; each
+        # falls through to the next if it cannot be set up on every rank or fails the cross-check
+        first = os.environ.get("SMPC_BENCH_EXCHANGE", "torch" if os.environ.get("SMPC_BENCH_TORCH_EXCHANGE") == "1"
+                               else "mailbox")
+        candidates = {"mailbox": ["mailbox", "rccl"], "rccl": ["rccl"], "torch": []}[first]
+        for kind in candidates:
             try:
-                # exchanges inside libsmpc: ncclAllGather on the ctx's stream between the kernels
-                so = NativeShardedOptimizer(g, speculate=not args.no_speculate)
-                exchange_impl = "RCCL called from libsmpc (smpc_shard_tick)"
-            except Exception as e:     # RCCL not loadable: same protocol through torch.distributed
-                print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed",
-                      file=sys.stderr, flush=True)
-        if so is not None:
-            # One tick through each implementation from the same state must give the same control
-            # sequence on every rank; otherwise (or if the native tick raises) every rank drops
-            # to the torch.distributed driver together.
-            agree = 0
-            try:
-                u_nat, o_nat = g.shard_tick(scn.tick, scn.u0, False)
-                u_ref, o_ref = ShardedOptimizer(HipShard(g), speculate=False).optimize(scn.tick, scn.u0)
-                agree = int(np.allclose(u_nat, u_ref, rtol=0, atol=1e-6) and
-                            o_nat.furthest_reached_path_point == o_ref.furthest_reached_path_point)
+                if kind == "mailbox":
+                    # no collective: tuples written into the peers' mailboxes over xGMI (smpc_shard_p2p_*)
+                    so = MailboxShardedOptimizer(g, speculate=not args.no_speculate)
+                    exchange_impl = "mailboxes over IPC/xGMI, no collective (smpc_shard_p2p_*, smpc_shard_tick)"
+                else:
+                    # exchanges inside libsmpc: ncclAllGather on the ctx's stream between the kernels
+                    so = NativeShardedOptimizer(g, speculate=not args.no_speculate)
+                    exchange_impl = "RCCL called from libsmpc (smpc_shard_tick)"
             except Exception as e:
-                print(f"[bench] rank {rank}: native exchange self-check raised: {e}", file=sys.stderr,
-                      flush=True)
-            g.set_stream(-1)      # SMPC_STREAM_OWN: back to the ctx's own stream
-            t = torch.tensor([agree], dtype=torch.int32, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) != 1:
-                print("[bench] native RCCL exchange disagrees with the torch.distributed driver; "
-                      "using torch.distributed", file=sys.stderr, flush=True)
+                print(f"[bench] {kind} exchange unavailable ({e})", file=sys.stderr, flush=True)
                 so = None
+                continue
+            if _exchange_agrees(g, scn, rank, HipShard, ShardedOptimizer, dist, torch):
+                break
+            print(f"[bench] {kind} exchange disagrees with the torch.distributed driver", file=sys.stderr,
+                  flush=True)
+            so = None
         if so is None:
             so = ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
             exchange_impl = "RCCL through torch.distributed (ShardedOptimizer)"

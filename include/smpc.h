@@ -496,6 +496,20 @@ int smpc_shard_comm_init(smpc_ctx* ctx, const void* id, int rank, int world);
 int smpc_shard_tick(smpc_ctx* ctx, const smpc_tick_in* in, float* u_inout, smpc_tick_out* out,
                     int speculate);
 
+/* The same tick with NO collective (the exchange is a few hundred bytes per rank: a library
+ * collective costs more in latency than it moves).  Every rank owns a mailbox in peer-visible
+ * device memory; smpc_shard_p2p_handle() creates it and returns its IPC handle
+ * (SMPC_P2P_HANDLE_BYTES), the caller hands every rank the handles of all ranks (rank order,
+ * world * SMPC_P2P_HANDLE_BYTES bytes) and smpc_shard_p2p_init() maps them.  From then on
+ * smpc_shard_tick() exchanges through the mailboxes: the finishing kernel of a rank writes its
+ * tuple into its peers' memory over xGMI and waits for theirs (bounded: a peer that never
+ * answers makes the tick fail with SMPC_ERR_DEVICE, it does not hang).  At most
+ * SMPC_P2P_MAX_WORLD ranks, all on one node; the Omni and DiffDrive models. */
+#define SMPC_P2P_HANDLE_BYTES 64
+#define SMPC_P2P_MAX_WORLD 16
+int smpc_shard_p2p_handle(smpc_ctx* ctx, void* handle_out, uint32_t handle_bytes);
+int smpc_shard_p2p_init(smpc_ctx* ctx, const void* handles, int rank, int world);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,6 +276,8 @@ PROTOTYPES = {
                                       C.POINTER(SmpcTickOut)]),
     "smpc_shard_comm_id": (C.c_int, [C.c_void_p, C.c_uint32]),
     "smpc_shard_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "smpc_shard_p2p_handle": (C.c_int, [_ctx, C.c_void_p, C.c_uint32]),
+    "smpc_shard_p2p_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "smpc_shard_tick": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p, C.POINTER(SmpcTickOut),
                                   C.c_int]),
 }

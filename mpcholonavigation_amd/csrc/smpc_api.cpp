@@ -51,6 +51,9 @@ void free_ctx(smpc_ctx* c)
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
   if (c->d_all) (void)hipFree(c->d_all);
+  for (uint32_t r = 0; r < c->p2p.world; ++r)
+    if (r != c->p2p.rank && c->p2p.peer[r]) (void)hipIpcCloseMemHandle(c->p2p.peer[r]);
+  if (c->p2p_mailbox) (void)hipFree(c->p2p_mailbox);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->evp) if (e) (void)hipEventDestroy(e);

@@ -45,6 +45,11 @@ hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
 hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float min_r, uint32_t seq,
                                  hipStream_t st);
+hipError_t smpc_launch_p2p_exchange(const float* my_tuple, const SmpcP2P& x, uint32_t T, int mode,
+                                    float* d_furthest, float neg_inv_temp, float vx_max, float vx_min,
+                                    float vy_max, float wz_max, float* u_out, float* result,
+                                    const float* furthest_used, float* host_out, uint32_t seq,
+                                    hipStream_t st);
 
 hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
 hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st);
@@ -152,6 +157,11 @@ struct smpc_ctx {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 0;
   float* d_all = nullptr;     // [world][4 + 3T] gathered shard tuples
+  // collective-free exchange (smpc_shard_p2p_*): the own mailbox (fine-grained device memory,
+  // exported over IPC) and the peers' mailboxes as mapped into this process
+  float* p2p_mailbox = nullptr;
+  SmpcP2P p2p{};               // world == 0: not set up
+  uint32_t p2p_xseq = 0;
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;

@@ -142,6 +142,15 @@ struct SmpcFinal {
   uint32_t seq;                            // tick sequence number published at u_host[3T+7]
 };
 
+// mailboxes of the collective-free shard exchange (smpc_p2p_exchange)
+#define SMPC_P2P_MAX_RANKS 16
+struct SmpcP2P {
+  float* peer[SMPC_P2P_MAX_RANKS];   // every rank's mailbox as mapped here; peer[rank] is the own one
+  uint32_t world, rank;
+  uint32_t slot_floats;              // floats per slot: the tuple, then the sequence word, padded
+  uint32_t xseq;                     // number of this exchange (1, 2, ...; parity picks the half)
+};
+
 // one planning instance's arguments of smpc_reduce_partials_many
 struct SmpcReduceArgs {
   const float* partials;

@@ -1157,16 +1157,15 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials_many(const SmpcRedu
 // rescale by exp(-(min_g - min)/temperature), divide by sum w, clip.
 // result: {min, sum_w, furthest, non_colliding}.  One block.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restrict__ tuples,
-                                                          uint32_t G, uint32_t T,
-                                                          float neg_inv_temp, float vx_max,
-                                                          float vx_min, float vy_max,
-                                                          float wz_max, float* __restrict__ u_out,
-                                                          float* __restrict__ result,
-                                                          const float* __restrict__ furthest_used,
-                                                          float* __restrict__ host_out, uint32_t seq)
+__device__ __forceinline__ void combine_tuples_body(const float* __restrict__ tuples, uint32_t stride,
+                                                    uint32_t G, uint32_t T, float neg_inv_temp,
+                                                    float vx_max, float vx_min, float vy_max,
+                                                    float wz_max, float* __restrict__ u_out,
+                                                    float* __restrict__ result,
+                                                    const float* __restrict__ furthest_used,
+                                                    float* __restrict__ host_out, uint32_t seq)
 {
-  const uint32_t TL = 4 + 3 * T;
+  const uint32_t TL = stride;
   float m = 3.0e38f, fu = 0.f, nc = 0.f;
   for (uint32_t g = 0; g < G; ++g) {
     m = fminf(m, tuples[(size_t)g * TL]);
@@ -1204,6 +1203,86 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
       __hip_atomic_store(reinterpret_cast<uint32_t*>(host_out + 3 * T + 7), seq, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+__global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restrict__ tuples,
+                                                          uint32_t G, uint32_t T,
+                                                          float neg_inv_temp, float vx_max,
+                                                          float vx_min, float vy_max,
+                                                          float wz_max, float* __restrict__ u_out,
+                                                          float* __restrict__ result,
+                                                          const float* __restrict__ furthest_used,
+                                                          float* __restrict__ host_out, uint32_t seq)
+{
+  combine_tuples_body(tuples, 4 + 3 * T, G, T, neg_inv_temp, vx_max, vx_min, vy_max, wz_max, u_out, result,
+                      furthest_used, host_out, seq);
+}
+
+// ---------------------------------------------------------------------------
+// Exchange of the shard tuples WITHOUT a collective (include/smpc.h smpc_shard_p2p_*): every
+// rank owns a mailbox in fine-grained device memory that its peers have mapped (IPC, xGMI):
+// [2 parities][world slots][slot_floats], the last word of a slot being its sequence number.
+// One block: copy this rank's tuple into slot `rank` of every mailbox, fence at system scope,
+// publish the sequence number; wait until every slot of the own mailbox carries it; then
+// combine as smpc_combine_tuples does (mode 0) or just take the maximum of the furthest points
+// (mode 1: the exchange of the non-speculative first tick).  Two parities: a rank can run at
+// most one exchange ahead of its slowest peer (it needs that peer's tuple to finish its own).
+// The wait is bounded (~1 s of shader clocks): on expiry host_out[3T + 6] = 1 and nothing
+// else is published, so a lost peer is an error of the tick, not a hang.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) smpc_p2p_exchange(const float* __restrict__ my_tuple,
+                                                        const SmpcP2P x, uint32_t T, int mode,
+                                                        float* __restrict__ d_furthest,
+                                                        float neg_inv_temp, float vx_max, float vx_min,
+                                                        float vy_max, float wz_max,
+                                                        float* __restrict__ u_out,
+                                                        float* __restrict__ result,
+                                                        const float* __restrict__ furthest_used,
+                                                        float* __restrict__ host_out, uint32_t seq)
+{
+  __shared__ int s_late;
+  const uint32_t TL = 4 + 3 * T, tid = threadIdx.x;
+  const size_t slot0 = (size_t)((x.xseq & 1u) * x.world) * x.slot_floats;
+  if (tid == 0) s_late = 0;
+  for (uint32_t r = 0; r < x.world; ++r) {
+    float* dst = x.peer[r] + slot0 + (size_t)x.rank * x.slot_floats;
+    for (uint32_t i = tid; i < TL; i += blockDim.x) dst[i] = my_tuple[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < x.world)
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(x.peer[tid] + slot0 + (size_t)x.rank * x.slot_floats + TL),
+                       x.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const float* mine = x.peer[x.rank] + slot0;
+  if (tid < x.world) {
+    const uint32_t* flag = reinterpret_cast<const uint32_t*>(mine + (size_t)tid * x.slot_floats + TL);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != x.xseq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memtime() - t0 > (1ull << 31)) {
+        s_late = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (s_late) {
+    if (tid == 0 && host_out) {
+      host_out[3 * T + 6] = 1.0f;
+      __threadfence_system();
+    }
+    return;
+  }
+  if (mode == 1) {
+    if (tid == 0) {
+      float fu = 0.f;
+      for (uint32_t r = 0; r < x.world; ++r) fu = fmaxf(fu, mine[(size_t)r * x.slot_floats + 2]);
+      *d_furthest = fu;
+    }
+    return;
+  }
+  combine_tuples_body(mine, x.slot_floats, x.world, T, neg_inv_temp, vx_max, vx_min, vy_max, wz_max, u_out,
+                      result, furthest_used, host_out, seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1413,6 +1492,18 @@ hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, floa
 {
   hipLaunchKernelGGL(smpc_combine_tuples, dim3(1), dim3(256), 0, st, tuples, G, T, neg_inv_temp,
                      vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used, host_out, seq);
+  return hipGetLastError();
+}
+
+hipError_t smpc_launch_p2p_exchange(const float* my_tuple, const SmpcP2P& x, uint32_t T, int mode,
+                                    float* d_furthest, float neg_inv_temp, float vx_max, float vx_min,
+                                    float vy_max, float wz_max, float* u_out, float* result,
+                                    const float* furthest_used, float* host_out, uint32_t seq,
+                                    hipStream_t st)
+{
+  hipLaunchKernelGGL(smpc_p2p_exchange, dim3(1), dim3(256), 0, st, my_tuple, x, T, mode, d_furthest,
+                     neg_inv_temp, vx_max, vx_min, vy_max, wz_max, u_out, result, furthest_used, host_out,
+                     seq);
   return hipGetLastError();
 }
 

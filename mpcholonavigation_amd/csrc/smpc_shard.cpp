@@ -136,11 +136,71 @@ int smpc_shard_comm_init(smpc_ctx* c, const void* id_in, int rank, int world)
     return fail(c, SMPC_ERR_DEVICE, std::string("ncclCommInitRank: ") +
                                    (r->GetErrorString ? r->GetErrorString(e) : "error"));
   }
+  // the last exchange set up is the one smpc_shard_tick uses: drop the mailboxes
+  for (uint32_t k = 0; k < c->p2p.world; ++k)
+    if (k != c->p2p.rank && c->p2p.peer[k]) (void)hipIpcCloseMemHandle(c->p2p.peer[k]);
+  c->p2p = SmpcP2P{};
   c->comm_rank = rank;
   c->comm_world = world;
   if (c->d_all) (void)hipFree(c->d_all);
   c->d_all = nullptr;
   HIPCK(c, hipMalloc(&c->d_all, static_cast<size_t>(world) * (4 + 3 * c->cfg.time_steps) * sizeof(float)));
+  return SMPC_OK;
+}
+
+// ---- exchange without a collective: mailboxes over IPC / xGMI (smpc_p2p_exchange) ----------
+static uint32_t p2p_slot_floats(uint32_t T) {return align_up(4 + 3 * T + 1, 16);}
+
+int smpc_shard_p2p_handle(smpc_ctx* c, void* handle_out, uint32_t handle_bytes)
+{
+  if (!c || !handle_out || handle_bytes < sizeof(hipIpcMemHandle_t))
+    return fail(c, SMPC_ERR_INVALID, "handle buffer too small");
+  HIPCK(c, hipSetDevice(c->device));
+  if (!c->p2p_mailbox) {
+    const size_t bytes = 2u * SMPC_P2P_MAX_RANKS * p2p_slot_floats(c->cfg.time_steps) * sizeof(float);
+    // fine-grained: stores arriving over xGMI must be visible to this GPU's loads without a
+    // cache flush in between
+    HIPCK(c, hipExtMallocWithFlags(reinterpret_cast<void**>(&c->p2p_mailbox), bytes, hipDeviceMallocFinegrained));
+    HIPCK(c, hipMemset(c->p2p_mailbox, 0, bytes));
+  }
+  hipIpcMemHandle_t h;
+  HIPCK(c, hipIpcGetMemHandle(&h, c->p2p_mailbox));
+  memcpy(handle_out, &h, sizeof(h));
+  return SMPC_OK;
+}
+
+int smpc_shard_p2p_init(smpc_ctx* c, const void* handles, int rank, int world)
+{
+  if (!c || !handles || world < 1 || world > SMPC_P2P_MAX_RANKS || rank < 0 || rank >= world)
+    return fail(c, SMPC_ERR_INVALID, "bad rank/world");
+  if (!c->p2p_mailbox) return fail(c, SMPC_ERR_STATE, "smpc_shard_p2p_handle first");
+  HIPCK(c, hipSetDevice(c->device));
+  for (uint32_t r = 0; r < c->p2p.world; ++r)
+    if (r != c->p2p.rank && c->p2p.peer[r]) (void)hipIpcCloseMemHandle(c->p2p.peer[r]);
+  c->p2p = SmpcP2P{};
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) {
+      c->p2p.peer[r] = c->p2p_mailbox;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const uint8_t*>(handles) + static_cast<size_t>(r) * sizeof(h), sizeof(h));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      c->p2p.world = static_cast<uint32_t>(r);   // what has been opened so far is closed with the ctx
+      c->p2p.rank = static_cast<uint32_t>(rank);
+      return fail(c, SMPC_ERR_DEVICE, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " +
+                                     hipGetErrorString(e));
+    }
+    c->p2p.peer[r] = static_cast<float*>(p);
+  }
+  c->p2p.world = static_cast<uint32_t>(world);
+  c->p2p.rank = static_cast<uint32_t>(rank);
+  c->p2p.slot_floats = p2p_slot_floats(c->cfg.time_steps);
+  c->p2p_xseq = 0;
+  c->comm_rank = rank;
+  c->comm_world = world;
   return SMPC_OK;
 }
 
@@ -152,8 +212,9 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
                     int speculate)
 {
   if (!c || !in || !u_inout) return fail(c, SMPC_ERR_INVALID, "null argument");
-  if (!c->comm) return fail(c, SMPC_ERR_STATE, "smpc_shard_comm_init first");
-  const RcclApi* r = rccl();
+  const bool p2p = c->p2p.world > 0;
+  if (!p2p && !c->comm) return fail(c, SMPC_ERR_STATE, "smpc_shard_comm_init or smpc_shard_p2p_init first");
+  const RcclApi* r = p2p ? nullptr : rccl();
   HIPCK(c, hipSetDevice(c->device));
   c->passes = 0;
   c->evp_used = 0;
@@ -165,7 +226,35 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
     if (e == ncclSuccess) return SMPC_OK;
     return fail(c, SMPC_ERR_DEVICE, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "error"));
   };
+  // mailbox exchange: publish the tuple to every peer, wait for theirs, combine — one launch
+  auto p2p_exchange = [&](int mode, const float* d_used) -> int {
+    SmpcP2P x = c->p2p;
+    x.xseq = ++c->p2p_xseq;
+    uint32_t seq = 0;
+    if (mode == 0 && c->poll_enabled) {
+      seq = ++c->seq;
+      if (seq == 0) seq = ++c->seq;
+      c->poll_seq = seq;
+    }
+    c->h_out[3 * T + 6] = 0.0f;   // the kernel's "a peer never answered" mark
+    HIPCK(c, smpc_launch_p2p_exchange(c->d_tuple, x, T, mode, c->d_furthest, c->dev.neg_inv_temp, c->c_vx_max,
+                                      c->c_vx_min, c->c_vy, c->c_wz, c->d_out, c->d_out + 3 * T, d_used,
+                                      c->h_out_dev, seq, c->stream));
+    if (mode == 0 && c->acker_r >= 0.f)
+      return fail(c, SMPC_ERR_UNSUPPORTED, "the mailbox exchange does not carry the Ackermann constraint");
+    return SMPC_OK;
+  };
+  auto p2p_check = [&]() -> int {
+    if (c->h_out[3 * T + 6] != 0.0f) return fail(c, SMPC_ERR_DEVICE, "shard exchange: a peer's tuple never arrived");
+    return SMPC_OK;
+  };
   auto gather_combine_fetch = [&](const float* d_used) -> int {
+    if (p2p) {
+      int e = p2p_exchange(0, d_used);
+      if (e != SMPC_OK) return e;
+      e = fetch_out(c);
+      return e != SMPC_OK ? e : p2p_check();
+    }
     int e = nccl_ok(r->AllGather(c->d_tuple, c->d_all, TL, ncclFloat32, c->comm, c->stream), "ncclAllGather");
     if (e != SMPC_OK) return e;
     e = launch_combine(c, c->d_all, G, d_used);
@@ -193,8 +282,14 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
     if (need_f) {
       rc = launch_furthest(c, c->d_furthest);
       if (rc != SMPC_OK) return rc;
-      rc = nccl_ok(r->AllReduce(c->d_furthest, c->d_furthest, 1, ncclFloat32, ncclMax, c->comm, c->stream),
-                   "ncclAllReduce");
+      if (p2p) {
+        // the local furthest point travels in field [2] of an otherwise empty tuple
+        HIPCK(c, hipMemcpyAsync(c->d_tuple + 2, c->d_furthest, sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        rc = p2p_exchange(1, nullptr);
+      } else {
+        rc = nccl_ok(r->AllReduce(c->d_furthest, c->d_furthest, 1, ncclFloat32, ncclMax, c->comm, c->stream),
+                     "ncclAllReduce");
+      }
       if (rc != SMPC_OK) return rc;
     }
     rc = launch_score(c, flags, nullptr, need_f ? c->d_furthest : nullptr, 0, c->d_tuple);

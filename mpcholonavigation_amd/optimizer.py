@@ -218,6 +218,19 @@ class Smpc:
         buf = (C.c_ubyte * A.SMPC_COMM_ID_BYTES).from_buffer_copy(comm_id)
         self._ck(self.lib.smpc_shard_comm_init(self.h, buf, int(rank), int(world)))
 
+    def shard_p2p_handle(self):
+        """IPC handle (bytes) of this context's mailbox for the collective-free exchange."""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.smpc_shard_p2p_handle(self.h, buf, 64))
+        return buf.raw
+
+    def shard_p2p_init(self, handles, rank, world):
+        """handles: the mailbox handles of all ranks, in rank order."""
+        if len(handles) != world or any(len(h) != 64 for h in handles):
+            raise ValueError("one 64-byte handle per rank")
+        blob = b"".join(handles)
+        self._ck(self.lib.smpc_shard_p2p_init(self.h, C.c_char_p(blob), rank, world))
+
     def shard_tick(self, tick, u, speculate=True):
         """One batch-sharded tick, ncclAllGather / ncclAllReduce included (collective)."""
         u = np.ascontiguousarray(u, dtype=np.float32).copy()

@@ -87,6 +87,46 @@ class NativeShardedOptimizer:
         return self.smpc.shard_tick(tick, u, self.speculate)
 
 
+class MailboxShardedOptimizer:
+    """The same tick with no collective at all (smpc_shard_p2p_*: every rank's finishing kernel
+    writes its tuple into its peers' mailboxes over xGMI and waits for theirs).
+    torch.distributed only ships the IPC handles of the mailboxes once.  Raises if the
+    mailboxes cannot be set up on every rank; the caller then falls back."""
+
+    def __init__(self, smpc, group=None, speculate=False):
+        self.smpc = smpc
+        self.speculate = speculate
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        try:
+            mine, ok = smpc.shard_p2p_handle(), 1
+        except Exception:
+            mine, ok = b"\0" * 64, 0
+        handles = [None] * world
+        if world > 1:
+            dist.all_gather_object(handles, (ok, mine), group=group)
+        else:
+            handles = [(ok, mine)]
+        if not all(o for o, _ in handles):
+            raise RuntimeError("the shard mailbox could not be created on every rank")
+        err = None
+        try:
+            smpc.shard_p2p_init([h for _, h in handles], rank, world)
+        except Exception as e:      # every rank must learn of it before anyone ticks
+            err = str(e)
+        errs = [None] * world
+        if world > 1:
+            dist.all_gather_object(errs, err, group=group)
+        else:
+            errs = [err]
+        if any(errs):
+            raise RuntimeError("the shard mailboxes could not be mapped: " + "; ".join(e for e in errs if e))
+        self.G = world
+
+    def optimize(self, tick, u):
+        return self.smpc.shard_tick(tick, u, self.speculate)
+
+
 class ShardedOptimizer:
     """Optimizer::optimize() over a batch sharded across the ranks of `group`."""
 

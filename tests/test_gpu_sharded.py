@@ -121,3 +121,97 @@ def test_native_rccl_tick_single_rank():
             u_n = np.concatenate([un[:, 1:], un[:, -1:]], axis=1)
     ref.close()
     nat.close()
+
+
+def test_mailbox_tick_single_rank():
+    """smpc_shard_tick over the collective-free mailbox exchange (smpc_shard_p2p_*) with one
+    rank equals the plain tick, speculating and not."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    from tests.helpers import make_case
+    cfg, scn, noise = make_case(4096, 40)
+    ref, box = Smpc(cfg), Smpc(cfg)
+    configure(ref, scn, noise=noise)
+    configure(box, scn, noise=noise)
+    box.shard_p2p_init([box.shard_p2p_handle()], 0, 1)
+    for speculate in (False, True):
+        u_r = u_n = scn.u0
+        for k in range(4):
+            ur, outr = ref.optimize(scn.tick, u_r)
+            un, outn = box.shard_tick(scn.tick, u_n, speculate)
+            assert outn.fail_flag == outr.fail_flag
+            assert outn.furthest_reached_path_point == outr.furthest_reached_path_point
+            assert outn.non_colliding == outr.non_colliding
+            np.testing.assert_allclose(un, ur, rtol=2e-6, atol=2e-7)
+            u_r = np.concatenate([ur[:, 1:], ur[:, -1:]], axis=1)
+            u_n = np.concatenate([un[:, 1:], un[:, -1:]], axis=1)
+    ref.close()
+    box.close()
+
+
+_MAILBOX_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SMPC_REPO"])
+from mpcholonavigation_amd.optimizer import Smpc
+from mpcholonavigation_amd.sharded import MailboxShardedOptimizer
+from mpcholonavigation_amd.tick import default_config
+from tests.helpers import configure, make_case
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, T = 8192, 40
+cfg, scn, noise = make_case(B, T)
+per = B // world
+a, b = rank * per, (rank + 1) * per
+sh = Smpc(default_config(batch_size=per, time_steps=T, shard_offset=a, global_batch_size=B))
+configure(sh, scn, noise=tuple(n[a:b] for n in noise))
+so = MailboxShardedOptimizer(sh, speculate=True)
+ref = None
+if rank == 0:
+    ref = Smpc(cfg)
+    configure(ref, scn, noise=noise)
+u_s = u_r = scn.u0
+for k in range(5):
+    us, outs = so.optimize(scn.tick, u_s)
+    got = [None] * world
+    dist.all_gather_object(got, us.tobytes())
+    assert all(g == got[0] for g in got), "ranks disagree"
+    if rank == 0:
+        ur, outr = ref.optimize(scn.tick, u_r)
+        assert outs.furthest_reached_path_point == outr.furthest_reached_path_point, k
+        assert outs.non_colliding == outr.non_colliding, k
+        np.testing.assert_allclose(us, ur, rtol=2e-5, atol=2e-6)
+        u_r = np.concatenate([ur[:, 1:], ur[:, -1:]], axis=1)
+    u_s = np.concatenate([us[:, 1:], us[:, -1:]], axis=1)
+dist.barrier()
+print("MAILBOX_OK", rank, flush=True)
+"""
+
+
+def test_mailbox_tick_two_processes_on_one_gpu(tmp_path):
+    """Two ranks (two processes sharing this GPU — the only multi-rank rehearsal a one-GPU box
+    allows) exchange their shard tuples through IPC-mapped mailboxes, no collective: both end
+    every tick with the same control sequence, which is the unsharded one.  Small batches, so
+    that the two processes' kernels fit on the GPU side by side."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "mailbox_worker.py"
+    script.write_text(_MAILBOX_WORKER)
+    env = dict(os.environ, SMPC_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"MAILBOX_OK {r}" in o, o[-3000:]
