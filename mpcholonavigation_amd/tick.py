@@ -42,9 +42,19 @@ class Tick:
             if self.path_pts_valid.shape != (max(len(self.path_x) - 1, 0),):
                 raise ValueError("path_pts_valid must have P-1 entries")
 
+    def __setattr__(self, name, value):
+        # any field assignment invalidates the cached C struct (arrays edited in place do not
+        # need to: the struct points at them)
+        object.__setattr__(self, name, value)
+        if name != "_c":
+            object.__setattr__(self, "_c", None)
+
     @property
     def c(self) -> A.SmpcTickIn:
-        """The C struct; arrays stay owned (and kept alive) by this object."""
+        """The C struct (built once per change of a field: it is on the tick's critical path);
+        arrays stay owned (and kept alive) by this object."""
+        if self._c is not None:
+            return self._c
         t = A.SmpcTickIn()
         t.pose_x, t.pose_y, t.pose_yaw = self.pose_x, self.pose_y, self.pose_yaw
         t.speed_vx, t.speed_vy, t.speed_wz = self.speed
