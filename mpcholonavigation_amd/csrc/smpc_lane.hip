@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   {
     const int ww = OBST ? p.win_w : 0, wh = OBST ? p.win_h : 0;
     const bool vec = OBST && ((ww & 3) == 0) && ((p.W & 3u) == 0) && ((p.win_x0 & 3) == 0);
-    const int w4 = ww >> 2, n4 = vec ? w4 * wh : 0;
+    const int w4 = OBST ? (ww >> 2) : 1, n4 = vec ? w4 * wh : 0;   // (1: the map-less variants never divide)
     auto word = [&](int i) -> uint32_t {
       const int ry = i / w4, rx = i - ry * w4;
       return reinterpret_cast<const uint32_t*>(p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0)[rx];
