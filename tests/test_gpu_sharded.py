@@ -189,21 +189,22 @@ print("MAILBOX_OK", rank, flush=True)
 """
 
 
-def test_mailbox_tick_two_processes_on_one_gpu(tmp_path):
-    """Two ranks (two processes sharing this GPU — the only multi-rank rehearsal a one-GPU box
-    allows) exchange their shard tuples through IPC-mapped mailboxes, no collective: both end
-    every tick with the same control sequence, which is the unsharded one.  Small batches, so
-    that the two processes' kernels fit on the GPU side by side."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_mailbox_tick_processes_on_one_gpu(tmp_path, world):
+    """Two and four ranks (processes sharing this GPU — the only multi-rank rehearsal a one-GPU
+    box allows) exchange their shard tuples through IPC-mapped mailboxes, no collective: all
+    end every tick with the same control sequence, which is the unsharded one.  Small batches,
+    so that the processes' kernels fit on the GPU side by side."""
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "mailbox_worker.py"
     script.write_text(_MAILBOX_WORKER)
-    env = dict(os.environ, SMPC_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SMPC_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + world),
+               WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
