@@ -295,6 +295,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    # SMPC_BENCH_SHARE_GPU=1 (with SMPC_BENCH_BACKEND=gloo): every rank on device 0 — a rehearsal
+    # of the N > 1 code path with several processes on a one-GPU box (small --rollouts-per-gpu)
+    if os.environ.get("SMPC_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # SMPC_BENCH_FORCE_DIST=1 drives the sharded path (RCCL collectives included) with a
     # single rank: a rehearsal of the N > 1 code path on a one-GPU box
@@ -304,7 +308,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SMPC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     B, T, MAP = args.rollouts_per_gpu, HORIZON, 200
     g, scn, cfg = make_ctx(B, T, MAP, shard_offset=rank * B, global_batch=world * B)
