@@ -146,11 +146,13 @@ class Smpc:
     # ---- hot path ----------------------------------------------------------
     def optimize(self, tick, u):
         """u: float32 [3, T] (vx, vy, wz) -> (u_new, SmpcTickOut)."""
-        u = np.ascontiguousarray(u, dtype=np.float32).copy()
+        u = np.array(u, dtype=np.float32, order="C")      # a copy: the call updates it in place
         if u.shape != (3, self.T):
             raise ValueError(f"u must be [3, {self.T}]")
         out = A.SmpcTickOut()
-        self._ck(self.lib.smpc_optimize(self.h, C.byref(tick.c), _ptr(u), C.byref(out)))
+        rc = self.lib.smpc_optimize(self.h, C.byref(tick.c), u.ctypes.data, C.byref(out))
+        if rc != 0:
+            self._ck(rc)
         return u, out
 
     def get_generated_trajectories(self):
