@@ -500,7 +500,8 @@ int smpc_shard_tick(smpc_ctx* ctx, const smpc_tick_in* in, float* u_inout, smpc_
  * collective costs more in latency than it moves).  Every rank owns a mailbox in peer-visible
  * device memory; smpc_shard_p2p_handle() creates it and returns its IPC handle
  * (SMPC_P2P_HANDLE_BYTES), the caller hands every rank the handles of all ranks (rank order,
- * world * SMPC_P2P_HANDLE_BYTES bytes) and smpc_shard_p2p_init() maps them.  From then on
+ * world * SMPC_P2P_HANDLE_BYTES bytes) and smpc_shard_p2p_init() maps them; the ranks must
+ * synchronise (any barrier) between that call and their first tick.  From then on
  * smpc_shard_tick() exchanges through the mailboxes: the finishing kernel of a rank writes its
  * tuple into its peers' memory over xGMI and waits for theirs (bounded: a peer that never
  * answers makes the tick fail with SMPC_ERR_DEVICE, it does not hang).  At most

@@ -198,6 +198,9 @@ int smpc_shard_p2p_init(smpc_ctx* c, const void* handles, int rank, int world)
   c->p2p.world = static_cast<uint32_t>(world);
   c->p2p.rank = static_cast<uint32_t>(rank);
   c->p2p.slot_floats = p2p_slot_floats(c->cfg.time_steps);
+  // a fresh numbering of the exchanges: no sequence word of an earlier set-up may survive in
+  // the own mailbox (the caller synchronises the ranks between this call and the first tick)
+  HIPCK(c, hipMemset(c->p2p_mailbox, 0, 2u * SMPC_P2P_MAX_RANKS * c->p2p.slot_floats * sizeof(float)));
   c->p2p_xseq = 0;
   c->comm_rank = rank;
   c->comm_world = world;
