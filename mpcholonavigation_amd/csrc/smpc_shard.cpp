@@ -162,6 +162,7 @@ int smpc_shard_p2p_handle(smpc_ctx* c, void* handle_out, uint32_t handle_bytes)
     // cache flush in between
     HIPCK(c, hipExtMallocWithFlags(reinterpret_cast<void**>(&c->p2p_mailbox), bytes, hipDeviceMallocFinegrained));
     HIPCK(c, hipMemset(c->p2p_mailbox, 0, bytes));
+    HIPCK(c, hipDeviceSynchronize());
   }
   hipIpcMemHandle_t h;
   HIPCK(c, hipIpcGetMemHandle(&h, c->p2p_mailbox));
@@ -201,6 +202,7 @@ int smpc_shard_p2p_init(smpc_ctx* c, const void* handles, int rank, int world)
   // a fresh numbering of the exchanges: no sequence word of an earlier set-up may survive in
   // the own mailbox (the caller synchronises the ranks between this call and the first tick)
   HIPCK(c, hipMemset(c->p2p_mailbox, 0, 2u * SMPC_P2P_MAX_RANKS * c->p2p.slot_floats * sizeof(float)));
+  HIPCK(c, hipDeviceSynchronize());   // (the ctx's stream is non-blocking: not ordered behind the memset)
   c->p2p_xseq = 0;
   c->comm_rank = rank;
   c->comm_world = world;
