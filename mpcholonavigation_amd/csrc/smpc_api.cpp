@@ -411,6 +411,8 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipMalloc(&c->d_furthest, 16));
   CK(hipMemset(c->d_furthest, 0, 16));
   CK(smpc_set_pass_lds_limit(static_cast<int>(kLdsPerCu)));
+  // the memsets above went to the default stream; the ctx works on its own non-blocking one
+  CK(hipDeviceSynchronize());
 #undef CK
   *out = c;
   return SMPC_OK;
