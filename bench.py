@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — rollouts/sec of one Optimizer::optimize() tick on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
 
 A "step" is one computeVelocityCommands() tick's optimize() call through the
 C-ABI (libsmpc.so): per-tick upload (control sequence, plan, tables), the
@@ -10,16 +10,27 @@ sequence.  The noise tensors and the costmap are resident in HBM before the
 timed region (the reference draws noise once per reset and reuses it,
 src/noise_generator.cpp:26-42).
 
-Workload (weak scaling): every GPU owns 262 144 rollouts x 64 steps on the
-200x200 synthetic costmap — BASELINE.json configs[3] (2 097 152 x 64 on 8 GPUs)
-is exactly the N=8 run; N=1 is its per-GPU shard.  configs[1] (65 536 x 64) and
-configs[2] (262 144 x 128, 2000x2000 map) are timed too at N=1 and reported
-under "other_configs".
+Workload (default, strong scaling): BASELINE.json configs[3] — 2 097 152 rollouts
+x 64 steps in total on the 200x200 synthetic costmap, the batch the metric is
+quoted on; N GPUs own 2 097 152 / N rollouts each (N = 1 runs the whole batch on
+one GPU).  `--scaling weak` keeps 262 144 rollouts per GPU instead (N = 8 is then
+the same job).  At N = 1 the other BASELINE configs are timed too and reported
+under "other_configs", together with three variants of the headline workload:
+the tick without furthest-point speculation, a closed loop with a moving pose,
+and regenerate_noises = true.
+
+At N > 1 the exchange is RCCL called from inside libsmpc (smpc_shard_tick: one
+ncclAllGather of the shard tuples per tick on the ctx's stream).  The
+collective-free mailbox exchange (smpc_shard_p2p_*) is timed next to it and
+reported under "exchange_alternatives"; SMPC_BENCH_EXCHANGE=mailbox|torch
+makes another implementation the headline.  Every fall-through is recorded in
+the JSON line (config.exchange_fallbacks), not only on stderr.
 
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,7 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SHARD_ROLLOUTS = 262144
+TOTAL_ROLLOUTS = 2097152       # BASELINE.json configs[3]
+SHARD_ROLLOUTS = 262144        # its per-GPU share at 8 GPUs (the --scaling weak workload)
 HORIZON = 64
 
 
@@ -42,10 +54,10 @@ def algorithmic_bytes(B, T, W, H, P):
 
 def measured_traffic(B, T, costmap):
     """HBM bytes per launch of the scoring pass from the committed rocprofv3 PMC passes
-    (profiles/<round>/traffic.json: FETCH_SIZE with the gfx950 x2 correction calibrated on the
+    (profiles/<round>/traffic*.json: FETCH_SIZE with the gfx950 x2 correction calibrated on the
     furthest-only pass + WRITE_SIZE) when one exists for exactly this workload, else None."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -63,7 +75,6 @@ def shift(u):
 
 
 def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0):
-    from mpcholonavigation_amd import _abi as A
     from mpcholonavigation_amd.optimizer import Smpc
     from mpcholonavigation_amd.synthetic import make_scenario
     from mpcholonavigation_amd.tick import default_config, default_critics
@@ -80,9 +91,13 @@ def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0)
     return g, scn, cfg
 
 
-def run_ticks(step_fn, scn, steps, warmup, sync, barrier):
+def run_ticks(step_fn, scn, steps, warmup, sync, barrier, before_tick=None):
+    """W untimed ticks, then exactly K timed ones between barrier + synchronize on both sides.
+    before_tick (e.g. smpc_redraw_noise) runs inside the timed region when given."""
     u = scn.u0
     for _ in range(warmup):
+        if before_tick:
+            before_tick()
         u_new, out = step_fn(scn.tick, u)
         u = shift(u_new)
     barrier()
@@ -91,6 +106,8 @@ def run_ticks(step_fn, scn, steps, warmup, sync, barrier):
     pass_ms = dev_ms = 0.0
     passes = 0
     for _ in range(steps):
+        if before_tick:
+            before_tick()
         u_new, out = step_fn(scn.tick, u)
         u = shift(u_new)
         pass_ms += out.score_pass_ms
@@ -102,23 +119,90 @@ def run_ticks(step_fn, scn, steps, warmup, sync, barrier):
     return (t1 - t0), pass_ms / steps, dev_ms / steps, passes / steps, out
 
 
-def time_config(B, T, map_size, steps, warmup):
+class MovingScene:
+    """Closed loop: the pose advances by the emitted Twist every tick (holonomic integration
+    over the controller period = model_dt) and the plan slides with it — a straight +x line on
+    a fixed 0.05 m grid, pruned to start at the grid point nearest behind the robot and cut
+    after `P` points, as PathHandler hands it over (src/path_handler.cpp:48-143).  Only the
+    optimize() calls are timed (their durations are summed): building the next tick's inputs
+    is the controller's job, not the optimizer's."""
+
+    def __init__(self, scn, dt):
+        from mpcholonavigation_amd.tick import Tick
+        self.Tick = Tick
+        self.scn = scn
+        self.dt = dt
+        t = scn.tick
+        self.x, self.y, self.yaw = t.pose_x, t.pose_y, t.pose_yaw
+        self.line_x0, self.line_y = float(t.path_x[0]), float(t.path_y[0])
+        self.P = len(t.path_x)
+        self.res = scn.resolution
+        self.x_wrap = self.line_x0 + 0.35 * scn.cells.shape[1] * scn.resolution   # stay on the map
+        self.speed = t.speed
+        self.wraps = 0
+
+    def tick(self):
+        k0 = max(0, int(math.floor((self.x - self.line_x0) / self.res)))
+        px = (self.line_x0 + self.res * (k0 + np.arange(self.P))).astype(np.float32)
+        py = np.full(self.P, self.line_y, np.float32)
+        return self.Tick(pose_x=self.x, pose_y=self.y, pose_yaw=self.yaw, speed=self.speed,
+                         path_x=px, path_y=py, path_yaw=np.zeros(self.P, np.float32),
+                         goal_x=float(px[-1]), goal_y=float(py[-1]))
+
+    def advance(self, u_new):
+        vx, vy, wz = (float(u_new[i, 1]) for i in range(3))    # Twist = u[offset = 1]
+        c, s = math.cos(self.yaw), math.sin(self.yaw)
+        self.x += (vx * c - vy * s) * self.dt
+        self.y += (vx * s + vy * c) * self.dt
+        self.yaw += wz * self.dt
+        self.speed = (vx, vy, wz)
+        if self.x > self.x_wrap:          # a new plan from the start (counts as what it is: a jump)
+            self.x, self.y, self.yaw = self.scn.tick.pose_x, self.scn.tick.pose_y, self.scn.tick.pose_yaw
+            self.wraps += 1
+
+
+def run_moving(step_fn, scn, dt, steps, warmup, sync, barrier):
+    mv = MovingScene(scn, dt)
+    u = scn.u0
+    el = 0.0
+    passes = 0
+    for k in range(warmup + steps):
+        tk = mv.tick()
+        if k >= warmup:
+            barrier()
+            sync()
+            t0 = time.perf_counter()
+        u_new, out = step_fn(tk, u)
+        if k >= warmup:
+            sync()
+            el += time.perf_counter() - t0
+            passes += out.passes
+        mv.advance(u_new)
+        u = shift(u_new)
+    return el, passes / steps, mv
+
+
+def time_config(B, T, map_size, steps, warmup, flags=0, redraw=False):
     import torch
-    g, scn, cfg = make_ctx(B, T, map_size)
+    g, scn, cfg = make_ctx(B, T, map_size, flags=flags)
+    before = g.redraw_noise if redraw else None
     el, _, _, passes, out = run_ticks(g.optimize, scn, steps, warmup,
-                                      torch.cuda.synchronize, lambda: None)
+                                      torch.cuda.synchronize, lambda: None, before_tick=before)
     g.set_profile(True)
-    _, pass_ms, dev_ms, _, _ = run_ticks(g.optimize, scn, steps, 2, torch.cuda.synchronize,
+    _, pass_ms, dev_ms, _, _ = run_ticks(g.optimize, scn, max(5, steps // 2), 2, torch.cuda.synchronize,
                                          lambda: None)
     P = len(scn.tick.path_x)
     by = algorithmic_bytes(B, T, map_size, map_size, P)
+    tick_s = el / steps
     r = {
         "rollouts_per_s": B * steps / el,
-        "ms_per_tick": 1e3 * el / steps,
+        "ms_per_tick": 1e3 * tick_s,
         "score_pass_ms": pass_ms,
         "device_ms": dev_ms,
         "algorithmic_bytes": by,
         "roofline_frac_score_pass": (by / (pass_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if pass_ms else None,
+        "roofline_frac_tick": (by / tick_s / 1e9) / HBM_PEAK_GBS,
+        "pass_kind": "lane per rollout" if out.pass_kind == 1 else "wave per rollout",
         "furthest": int(out.furthest_reached_path_point),
         "passes_per_tick": passes,
     }
@@ -249,35 +333,59 @@ def cpu_baseline(T, map_size, budget_s=12.0, B=65536, max_ticks=200):
         pass
     return {
         "value": B * n / el, "unit": "rollouts/s", "cores": 1, "kind": "port",
-        "sample": f"{n} ticks of {B} rollouts x {T} steps, {map_size}x{map_size} costmap, "
+        "sample": f"{n} ticks of {B} rollouts x {T} steps (a bounded sample: rollouts/s of the CPU path does not "
+                  f"depend on the batch size), {map_size}x{map_size} costmap, "
                   f"oracle built -O3 -mavx2 -mfma -ffast-math; host {cpu}, "
                   f"{os.cpu_count()} logical cores present",
     }
 
 
+def _all_min(dist, torch, v):
+    t = torch.tensor([int(v)], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def _exchange_agrees(g, scn, rank, HipShard, ShardedOptimizer, dist, torch):
     """One tick through smpc_shard_tick (whichever exchange the ctx is set up for) and one through
     the torch.distributed driver from the same state must give the same control sequence on every
-    rank; the verdict is shared, so that every rank keeps or drops the implementation together."""
-    agree = 0
+    rank.  The ranks stay in lockstep: the outcome of the library tick is shared (all_reduce MIN)
+    BEFORE anyone enters the reference tick's collectives, and so is the verdict, so that every
+    rank keeps or drops the implementation together.  Returns (ok, reason)."""
+    note = ""
     try:
         u_nat, o_nat = g.shard_tick(scn.tick, scn.u0, False)
+        ok = 1
+    except Exception as e:
+        ok, note = 0, f"rank {rank}: shard_tick raised: {e}"
+        print(f"[bench] {note}", file=sys.stderr, flush=True)
+    if not _all_min(dist, torch, ok):
+        return False, note or "shard_tick failed on another rank"
+    agree = 0
+    try:
         u_ref, o_ref = ShardedOptimizer(HipShard(g), speculate=False).optimize(scn.tick, scn.u0)
         agree = int(np.allclose(u_nat, u_ref, rtol=0, atol=1e-6) and
                     o_nat.furthest_reached_path_point == o_ref.furthest_reached_path_point)
+        if not agree:
+            note = f"rank {rank}: control sequence differs from the torch.distributed driver's"
     except Exception as e:
-        print(f"[bench] rank {rank}: exchange self-check raised: {e}", file=sys.stderr, flush=True)
+        note = f"rank {rank}: reference tick raised: {e}"
+        print(f"[bench] {note}", file=sys.stderr, flush=True)
     g.set_stream(-1)      # SMPC_STREAM_OWN: back to the ctx's own stream
-    t = torch.tensor([agree], dtype=torch.int32, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return int(t.item()) == 1
+    if not _all_min(dist, torch, agree):
+        return False, note or "disagreement on another rank"
+    return True, ""
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): --total-rollouts in all, split over the GPUs; "
+                         "weak: --rollouts-per-gpu on every GPU")
+    ap.add_argument("--total-rollouts", type=int, default=TOTAL_ROLLOUTS)
     ap.add_argument("--rollouts-per-gpu", type=int, default=SHARD_ROLLOUTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -296,14 +404,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     # SMPC_BENCH_SHARE_GPU=1 (with SMPC_BENCH_BACKEND=gloo): every rank on device 0 — a rehearsal
-    # of the N > 1 code path with several processes on a one-GPU box (small --rollouts-per-gpu)
+    # of the N > 1 code path with several processes on a one-GPU box (small --total-rollouts)
     if os.environ.get("SMPC_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     # SMPC_BENCH_FORCE_DIST=1 drives the sharded path (RCCL collectives included) with a
     # single rank: a rehearsal of the N > 1 code path on a one-GPU box
     force_dist = os.environ.get("SMPC_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
+    sharded = world > 1 or force_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -314,42 +423,61 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    B, T, MAP = args.rollouts_per_gpu, HORIZON, 200
+    T, MAP = HORIZON, 200
+    if args.scaling == "strong":
+        if args.total_rollouts % world:
+            raise SystemExit(f"--total-rollouts {args.total_rollouts} is not divisible by {world} GPUs")
+        B = args.total_rollouts // world
+    else:
+        B = args.rollouts_per_gpu
     g, scn, cfg = make_ctx(B, T, MAP, shard_offset=rank * B, global_batch=world * B)
     P = len(scn.tick.path_x)
 
     exchange_impl = "none"
-    if world > 1 or force_dist:
+    fallbacks = []          # every implementation tried and dropped, with the reason
+    alternatives = {}
+    if sharded:
         from mpcholonavigation_amd.sharded import (HipShard, MailboxShardedOptimizer, NativeShardedOptimizer,
                                                    ShardedOptimizer)
-        so = None
-        # SMPC_BENCH_EXCHANGE = mailbox | rccl | torch picks the first implementation tried; each
-        # falls through to the next if it cannot be set up on every rank or fails the cross-check
-        first = os.environ.get("SMPC_BENCH_EXCHANGE", "torch" if os.environ.get("SMPC_BENCH_TORCH_EXCHANGE") == "1"
-                               else "mailbox")
-        candidates = {"mailbox": ["mailbox", "rccl"], "rccl": ["rccl"], "torch": []}[first]
-        for kind in candidates:
+        labels = {
+            "rccl": "RCCL called from libsmpc (smpc_shard_tick: ncclAllGather on the ctx's stream)",
+            "mailbox": "mailboxes over IPC/xGMI, no collective (smpc_shard_p2p_*, smpc_shard_tick)",
+            "torch": "RCCL through torch.distributed (ShardedOptimizer)",
+        }
+
+        def set_up(kind):
+            """-> optimizer or None; collective; records the reason of a failure."""
+            if kind == "torch":
+                g.set_stream(-1)
+                return ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
             try:
-                if kind == "mailbox":
-                    # no collective: tuples written into the peers' mailboxes over xGMI (smpc_shard_p2p_*)
-                    so = MailboxShardedOptimizer(g, speculate=not args.no_speculate)
-                    exchange_impl = "mailboxes over IPC/xGMI, no collective (smpc_shard_p2p_*, smpc_shard_tick)"
-                else:
-                    # exchanges inside libsmpc: ncclAllGather on the ctx's stream between the kernels
-                    so = NativeShardedOptimizer(g, speculate=not args.no_speculate)
-                    exchange_impl = "RCCL called from libsmpc (smpc_shard_tick)"
+                cls = MailboxShardedOptimizer if kind == "mailbox" else NativeShardedOptimizer
+                so = cls(g, speculate=not args.no_speculate)
+                err = ""
             except Exception as e:
-                print(f"[bench] {kind} exchange unavailable ({e})", file=sys.stderr, flush=True)
-                so = None
-                continue
-            if _exchange_agrees(g, scn, rank, HipShard, ShardedOptimizer, dist, torch):
+                so, err = None, f"set-up failed: {e}"
+            if not _all_min(dist, torch, so is not None):
+                fallbacks.append({"tried": kind, "reason": err or "set-up failed on another rank"})
+                return None
+            ok, why = _exchange_agrees(g, scn, rank, HipShard, ShardedOptimizer, dist, torch)
+            g.reset()      # every rank back to the same state (no furthest-point hint), dropped or kept
+            if not ok:
+                fallbacks.append({"tried": kind, "reason": "cross-check against the torch.distributed driver: " + why})
+                return None
+            return so
+
+        # SMPC_BENCH_EXCHANGE = rccl (default) | mailbox | torch picks the headline implementation;
+        # each falls through to the next if it cannot be set up on every rank or fails the
+        # cross-check.  north_star names the RCCL collective: it is the default.
+        first = os.environ.get("SMPC_BENCH_EXCHANGE", "rccl")
+        order = {"rccl": ["rccl", "torch"], "mailbox": ["mailbox", "rccl", "torch"], "torch": ["torch"]}[first]
+        so = None
+        for kind in order:
+            so = set_up(kind)
+            if so is not None:
+                exchange_impl = labels[kind]
+                headline_kind = kind
                 break
-            print(f"[bench] {kind} exchange disagrees with the torch.distributed driver", file=sys.stderr,
-                  flush=True)
-            so = None
-        if so is None:
-            so = ShardedOptimizer(HipShard(g), speculate=not args.no_speculate)
-            exchange_impl = "RCCL through torch.distributed (ShardedOptimizer)"
         step_fn = so.optimize
 
         def barrier():
@@ -369,38 +497,83 @@ def main():
     g.set_profile(True)
     el_prof, pass_ms, dev_ms, _, _ = run_ticks(step_fn, scn, args.steps, 2,
                                                torch.cuda.synchronize, barrier)
-    if world > 1 or force_dist:
-        t = torch.tensor([el, pass_ms], dtype=torch.float64, device="cuda")
+    g.set_profile(False)
+    # the same workload with a moving pose (closed loop; the furthest point changes as the robot
+    # advances, so the speculation of a frozen scene does not flatter the tick)
+    el_mv, passes_mv, mv = run_moving(step_fn, scn, cfg.model_dt, args.steps, min(args.warmup, 5),
+                                      torch.cuda.synchronize, barrier)
+    if sharded:
+        t = torch.tensor([el, pass_ms, el_mv], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, pass_ms = float(t[0]), float(t[1])
+        el, pass_ms, el_mv = float(t[0]), float(t[1]), float(t[2])
+
+    # N > 1: the exchange implementations that are not the headline, timed on the same workload
+    if world > 1 and os.environ.get("SMPC_BENCH_ALTERNATIVES", "1") != "0":
+        for kind in ("rccl", "mailbox", "torch"):
+            if kind == headline_kind:
+                continue
+            n_fb = len(fallbacks)
+            alt = set_up(kind)
+            if alt is None:
+                alternatives[kind] = {"error": fallbacks[-1]["reason"] if len(fallbacks) > n_fb else "unavailable"}
+                del fallbacks[n_fb:]
+                continue
+            ok, el_a, p_a = 1, 0.0, 0.0
+            try:
+                el_a, _, _, p_a, _ = run_ticks(alt.optimize, scn, args.steps, args.warmup,
+                                               torch.cuda.synchronize, barrier)
+            except Exception as e:
+                ok = 0
+                alternatives[kind] = {"error": f"rank {rank}: {e}"}
+            if not _all_min(dist, torch, ok):
+                alternatives.setdefault(kind, {"error": "failed on another rank"})
+                g.reset()
+                continue
+            t = torch.tensor([el_a], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            alternatives[kind] = {"exchange_impl": labels[kind], "ms_per_step": 1e3 * float(t[0]) / args.steps,
+                                  "rollouts_per_s": world * B * args.steps / float(t[0]),
+                                  "scoring_passes_per_tick": p_a}
+            g.reset()
+        g.set_stream(-1)
 
     if rank == 0:
         by = algorithmic_bytes(B, T, MAP, MAP, P)
         achieved = by / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        tick_s = el / args.steps
+        # tick level, SURVEY §8(d): the GPU's algorithmic bytes of ONE scoring pass over the whole
+        # tick's wall time (uploads, every pass incl. re-scores, reduction, exchange, read-back)
+        achieved_tick = by / tick_s / 1e9
         traffic, traffic_src = measured_traffic(B, T, f"{MAP}x{MAP}")
+        total = world * B
         line = {
             "metric": "rollouts/sec per computeVelocityCommands() tick",
-            "value": world * B * cfg.iteration_count * args.steps / el,
+            "value": total * cfg.iteration_count * args.steps / el,
             "unit": "rollouts/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps,
+            "ms_per_step": 1e3 * tick_s,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[3] weak-scaled: {B} rollouts x {T} steps per GPU "
-                            f"({world * B} total), full critic stack, 200x200 costmap in LDS, "
-                            "stored noise (HBM resident), iteration_count 1",
-                "rollouts_per_gpu": B, "horizon": T, "costmap": "200x200", "path_points": P,
+                "workload": (f"BASELINE configs[3]: {total} rollouts x {T} steps in total"
+                             + (f" on one GPU" if world == 1 else f", {B} per GPU on {world} GPUs")
+                             + (" (strong scaling: the total is fixed)" if args.scaling == "strong"
+                                else " (weak scaling: the per-GPU share is fixed)")
+                             + ", full critic stack, 200x200 costmap in LDS, stored noise (HBM resident), "
+                               "iteration_count 1"),
+                "total_rollouts": total, "rollouts_per_gpu": B, "horizon": T, "costmap": "200x200",
+                "path_points": P,
                 "critics": ["Obstacles", "PathAlign", "PathFollow", "GoalAngle", "PreferForward"],
                 "exchange": ("none" if world == 1 else
                              ("all_reduce(max furthest) + all_gather(tuple)" if args.no_speculate else
                               "all_gather(tuple); furthest point speculated, re-scored on a miss")),
                 "exchange_impl": exchange_impl,
+                "exchange_fallbacks": fallbacks,
                 "furthest_reached_path_point": int(out.furthest_reached_path_point),
                 "scoring_passes_per_tick": passes,
             },
@@ -411,19 +584,39 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": by,
                 "avg_launch_ms": pass_ms,
+                "achieved_tick": achieved_tick,
+                "frac_tick": achieved_tick / HBM_PEAK_GBS,
+                "frac_note": "frac: algorithmic bytes of one launch / average duration of the scoring-pass "
+                             "kernel; frac_tick: the same bytes / wall time of the whole tick (SURVEY 8(d))",
                 "device_ms_per_tick": dev_ms,
-                "timing": f"HIP events around each smpc_pass launch over {args.steps} further ticks "
+                "timing": f"HIP events around each scoring-pass launch over {args.steps} further ticks "
                           f"({1e3 * el_prof / args.steps:.4f} ms/tick with the event records in the stream)",
             },
+            "moving_pose": {
+                "ms_per_step": 1e3 * el_mv / args.steps,
+                "rollouts_per_s": total * args.steps / el_mv,
+                "scoring_passes_per_tick": passes_mv,
+                "frac_tick": (by / (el_mv / args.steps) / 1e9) / HBM_PEAK_GBS,
+                "note": "closed loop: pose advanced by the emitted Twist every tick, plan pruned to the "
+                        f"robot; optimize() calls only ({mv.wraps} plan restarts)",
+            },
         }
+        if alternatives:
+            line["exchange_alternatives"] = alternatives
         if world == 1 and not args.no_other_configs:
+            from mpcholonavigation_amd import _abi as A
+            k4 = max(20, args.steps // 4)
             line["other_configs"] = {
-                "configs[1] 65536x64 200x200": time_config(65536, 64, 200, args.steps, args.warmup),
-                "configs[2] 262144x128 2000x2000": time_config(262144, 128, 2000,
-                                                                max(20, args.steps // 4),
-                                                                max(5, args.warmup // 4)),
+                "configs[1] 65536x64 200x200": time_config(65536, 64, 200, 2 * args.steps, 2 * args.warmup),
+                "configs[2] 262144x128 2000x2000": time_config(262144, 128, 2000, k4, 5),
+                "configs[3] per-GPU share at 8 GPUs 262144x64 200x200":
+                    time_config(SHARD_ROLLOUTS, 64, MAP, 2 * args.steps, 2 * args.warmup),
                 "configs[4] 8 queries x 16384x64 per GPU": time_multi_query(8, 16384, 64, MAP,
-                                                                            args.steps, args.warmup),
+                                                                            2 * args.steps, 2 * args.warmup),
+                f"{B}x64 without speculation (furthest-only pass + scoring pass every tick)":
+                    time_config(B, T, MAP, k4, 3, flags=A.SMPC_FLAG_NO_SPECULATION),
+                f"{B}x64 regenerate_noises=true (device RNG redraw inside every tick)":
+                    time_config(B, T, MAP, k4, 3, redraw=True),
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, MAP)
@@ -438,7 +631,7 @@ def main():
                 "gpu_rollouts_per_s": g0["rollouts_per_s"], "gpu_ms_per_tick": g0["ms_per_tick"]}
         print(json.dumps(line), flush=True)
     g.close()
-    if world > 1 or force_dist:
+    if sharded:
         dist.destroy_process_group()
 
 

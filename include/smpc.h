@@ -503,13 +503,21 @@ int smpc_shard_tick(smpc_ctx* ctx, const smpc_tick_in* in, float* u_inout, smpc_
  * world * SMPC_P2P_HANDLE_BYTES bytes) and smpc_shard_p2p_init() maps them; the ranks must
  * synchronise (any barrier) between that call and their first tick.  From then on
  * smpc_shard_tick() exchanges through the mailboxes: the finishing kernel of a rank writes its
- * tuple into its peers' memory over xGMI and waits for theirs (bounded: a peer that never
- * answers makes the tick fail with SMPC_ERR_DEVICE, it does not hang).  At most
- * SMPC_P2P_MAX_WORLD ranks, all on one node; the Omni and DiffDrive models. */
+ * tuple into its peers' memory over xGMI and waits for theirs.  The wait is bounded in
+ * wall-clock time (default 10 000 ms, smpc_shard_p2p_set_timeout): it has to cover the skew
+ * between the ranks' calls, not just the exchange.  A peer that does not answer in time makes
+ * the tick fail with SMPC_ERR_DEVICE, it does not hang; the failed rank then stops publishing
+ * and every later smpc_shard_tick on it returns SMPC_ERR_STATE, so its peers fail at their
+ * next exchange at the latest (they may have completed the tick the failed rank lost: treat
+ * any failure as "exchange down on all ranks": smpc_shard_p2p_init again on every rank, then
+ * smpc_reset).  At most SMPC_P2P_MAX_WORLD ranks, all on one node; the Omni and DiffDrive
+ * models (smpc_shard_p2p_init refuses an Ackermann ctx).  This exchange is an opt-in
+ * optimisation; the RCCL exchange above is the default a sharded deployment should start with. */
 #define SMPC_P2P_HANDLE_BYTES 64
 #define SMPC_P2P_MAX_WORLD 16
 int smpc_shard_p2p_handle(smpc_ctx* ctx, void* handle_out, uint32_t handle_bytes);
 int smpc_shard_p2p_init(smpc_ctx* ctx, const void* handles, int rank, int world);
+int smpc_shard_p2p_set_timeout(smpc_ctx* ctx, uint32_t milliseconds);
 
 #ifdef __cplusplus
 }

@@ -278,6 +278,7 @@ PROTOTYPES = {
     "smpc_shard_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "smpc_shard_p2p_handle": (C.c_int, [_ctx, C.c_void_p, C.c_uint32]),
     "smpc_shard_p2p_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "smpc_shard_p2p_set_timeout": (C.c_int, [_ctx, C.c_uint32]),
     "smpc_shard_tick": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p, C.POINTER(SmpcTickOut),
                                   C.c_int]),
 }

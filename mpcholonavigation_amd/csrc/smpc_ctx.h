@@ -162,6 +162,8 @@ struct smpc_ctx {
   float* p2p_mailbox = nullptr;
   SmpcP2P p2p{};               // world == 0: not set up
   uint32_t p2p_xseq = 0;
+  uint32_t p2p_timeout_ms = 10000;   // bound of the in-kernel wait for the peers (smpc_shard_p2p_set_timeout)
+  bool p2p_failed = false;           // an exchange timed out: no further mailbox tick until re-init
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;

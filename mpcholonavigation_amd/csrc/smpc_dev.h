@@ -149,6 +149,8 @@ struct SmpcP2P {
   uint32_t world, rank;
   uint32_t slot_floats;              // floats per slot: the tuple, then the sequence word, padded
   uint32_t xseq;                     // number of this exchange (1, 2, ...; parity picks the half)
+  uint32_t* state;                   // device word: 0 healthy, else an exchange of this ctx timed out
+  unsigned long long timeout_ticks;  // bound of the wait in s_memrealtime ticks (10 ns each)
 };
 
 // one planning instance's arguments of smpc_reduce_partials_many

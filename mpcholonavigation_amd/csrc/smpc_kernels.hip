@@ -1227,8 +1227,14 @@ __global__ void __launch_bounds__(256) smpc_combine_tuples(const float* __restri
 // combine as smpc_combine_tuples does (mode 0) or just take the maximum of the furthest points
 // (mode 1: the exchange of the non-speculative first tick).  Two parities: a rank can run at
 // most one exchange ahead of its slowest peer (it needs that peer's tuple to finish its own).
-// The wait is bounded (~1 s of shader clocks): on expiry host_out[3T + 6] = 1 and nothing
-// else is published, so a lost peer is an error of the tick, not a hang.
+//
+// The wait is bounded in WALL-CLOCK time (s_memrealtime, a constant 100 MHz counter:
+// x.timeout_ticks of 10 ns each).  On expiry the block sets *x.state (sticky, device memory) and
+// host_out[3T + 6] = 1, publishes the completion word so that the host returns at once, and
+// publishes nothing else.  Every later exchange of this ctx sees *x.state != 0 on entry and
+// does the same WITHOUT writing to any peer: a rank that failed once stays silent, so its peers
+// fail at their next exchange at the latest instead of consuming tuples of a rank whose own
+// tick was lost.  Only smpc_shard_p2p_init (collective) clears the state.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) smpc_p2p_exchange(const float* __restrict__ my_tuple,
                                                         const SmpcP2P x, uint32_t T, int mode,
@@ -1243,23 +1249,26 @@ __global__ void __launch_bounds__(256) smpc_p2p_exchange(const float* __restrict
   __shared__ int s_late;
   const uint32_t TL = 4 + 3 * T, tid = threadIdx.x;
   const size_t slot0 = (size_t)((x.xseq & 1u) * x.world) * x.slot_floats;
-  if (tid == 0) s_late = 0;
-  for (uint32_t r = 0; r < x.world; ++r) {
-    float* dst = x.peer[r] + slot0 + (size_t)x.rank * x.slot_floats;
-    for (uint32_t i = tid; i < TL; i += blockDim.x) dst[i] = my_tuple[i];
-  }
-  __threadfence_system();
+  if (tid == 0) s_late = (__hip_atomic_load(x.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 2 : 0;
   __syncthreads();
-  if (tid < x.world)
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(x.peer[tid] + slot0 + (size_t)x.rank * x.slot_floats + TL),
-                       x.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (s_late == 0) {
+    for (uint32_t r = 0; r < x.world; ++r) {
+      float* dst = x.peer[r] + slot0 + (size_t)x.rank * x.slot_floats;
+      for (uint32_t i = tid; i < TL; i += blockDim.x) dst[i] = my_tuple[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < x.world)
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(x.peer[tid] + slot0 + (size_t)x.rank * x.slot_floats + TL),
+                         x.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const float* mine = x.peer[x.rank] + slot0;
-  if (tid < x.world) {
+  if (s_late == 0 && tid < x.world) {
     const uint32_t* flag = reinterpret_cast<const uint32_t*>(mine + (size_t)tid * x.slot_floats + TL);
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != x.xseq) {
       __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memtime() - t0 > (1ull << 31)) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > x.timeout_ticks) {
         s_late = 1;
         break;
       }
@@ -1267,9 +1276,15 @@ __global__ void __launch_bounds__(256) smpc_p2p_exchange(const float* __restrict
   }
   __syncthreads();
   if (s_late) {
-    if (tid == 0 && host_out) {
-      host_out[3 * T + 6] = 1.0f;
-      __threadfence_system();
+    if (tid == 0) {
+      __hip_atomic_store(x.state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (host_out) {
+        host_out[3 * T + 6] = 1.0f;
+        __threadfence_system();
+        if (seq)
+          __hip_atomic_store(reinterpret_cast<uint32_t*>(host_out + 3 * T + 7), seq, __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     return;
   }

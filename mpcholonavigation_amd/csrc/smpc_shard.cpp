@@ -151,6 +151,14 @@ int smpc_shard_comm_init(smpc_ctx* c, const void* id_in, int rank, int world)
 // ---- exchange without a collective: mailboxes over IPC / xGMI (smpc_p2p_exchange) ----------
 static uint32_t p2p_slot_floats(uint32_t T) {return align_up(4 + 3 * T + 1, 16);}
 
+int smpc_shard_p2p_set_timeout(smpc_ctx* c, uint32_t milliseconds)
+{
+  if (!c || milliseconds == 0) return fail(c, SMPC_ERR_INVALID, "timeout must be > 0 ms");
+  c->p2p_timeout_ms = milliseconds;
+  c->p2p.timeout_ticks = static_cast<unsigned long long>(milliseconds) * 100000ull;
+  return SMPC_OK;
+}
+
 int smpc_shard_p2p_handle(smpc_ctx* c, void* handle_out, uint32_t handle_bytes)
 {
   if (!c || !handle_out || handle_bytes < sizeof(hipIpcMemHandle_t))
@@ -175,7 +183,12 @@ int smpc_shard_p2p_init(smpc_ctx* c, const void* handles, int rank, int world)
   if (!c || !handles || world < 1 || world > SMPC_P2P_MAX_RANKS || rank < 0 || rank >= world)
     return fail(c, SMPC_ERR_INVALID, "bad rank/world");
   if (!c->p2p_mailbox) return fail(c, SMPC_ERR_STATE, "smpc_shard_p2p_handle first");
+  // AckermannMotionModel::applyConstraints needs a launch of its own behind the combine
+  // (smpc_ackermann_constrain); the exchange kernel is the tick's last launch
+  if (c->acker_r >= 0.f)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "the mailbox exchange does not carry the Ackermann constraint");
   HIPCK(c, hipSetDevice(c->device));
+  HIPCK(c, hipStreamSynchronize(c->stream));   // no exchange of an earlier set-up may still run
   for (uint32_t r = 0; r < c->p2p.world; ++r)
     if (r != c->p2p.rank && c->p2p.peer[r]) (void)hipIpcCloseMemHandle(c->p2p.peer[r]);
   c->p2p = SmpcP2P{};
@@ -202,7 +215,14 @@ int smpc_shard_p2p_init(smpc_ctx* c, const void* handles, int rank, int world)
   // a fresh numbering of the exchanges: no sequence word of an earlier set-up may survive in
   // the own mailbox (the caller synchronises the ranks between this call and the first tick)
   HIPCK(c, hipMemset(c->p2p_mailbox, 0, 2u * SMPC_P2P_MAX_RANKS * c->p2p.slot_floats * sizeof(float)));
-  HIPCK(c, hipDeviceSynchronize());   // (the ctx's stream is non-blocking: not ordered behind the memset)
+  // the sticky "an exchange timed out" word (device) and its host-visible mark: only this
+  // collective set-up clears them
+  c->p2p.state = reinterpret_cast<uint32_t*>(c->d_furthest) + 3;
+  HIPCK(c, hipMemset(c->p2p.state, 0, sizeof(uint32_t)));
+  HIPCK(c, hipDeviceSynchronize());   // (the ctx's stream is non-blocking: not ordered behind the memsets)
+  c->h_out[3 * c->cfg.time_steps + 6] = 0.0f;
+  c->p2p_failed = false;
+  c->p2p.timeout_ticks = static_cast<unsigned long long>(c->p2p_timeout_ms) * 100000ull;   // 100 MHz
   c->p2p_xseq = 0;
   c->comm_rank = rank;
   c->comm_world = world;
@@ -219,6 +239,10 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
   if (!c || !in || !u_inout) return fail(c, SMPC_ERR_INVALID, "null argument");
   const bool p2p = c->p2p.world > 0;
   if (!p2p && !c->comm) return fail(c, SMPC_ERR_STATE, "smpc_shard_comm_init or smpc_shard_p2p_init first");
+  if (p2p && c->p2p_failed)
+    return fail(c, SMPC_ERR_STATE,
+                "an earlier mailbox exchange timed out: this rank no longer publishes (its peers fail at their "
+                "next exchange); set the exchange up again on every rank (smpc_shard_p2p_init) and smpc_reset");
   const RcclApi* r = p2p ? nullptr : rccl();
   HIPCK(c, hipSetDevice(c->device));
   c->passes = 0;
@@ -241,17 +265,23 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
       if (seq == 0) seq = ++c->seq;
       c->poll_seq = seq;
     }
-    c->h_out[3 * T + 6] = 0.0f;   // the kernel's "a peer never answered" mark
+    // (h_out[3T + 6], the kernel's "a peer never answered" mark, is cleared by
+    // smpc_shard_p2p_init only: the device may write it at any time after a launch)
     HIPCK(c, smpc_launch_p2p_exchange(c->d_tuple, x, T, mode, c->d_furthest, c->dev.neg_inv_temp, c->c_vx_max,
                                       c->c_vx_min, c->c_vy, c->c_wz, c->d_out, c->d_out + 3 * T, d_used,
                                       c->h_out_dev, seq, c->stream));
-    if (mode == 0 && c->acker_r >= 0.f)
-      return fail(c, SMPC_ERR_UNSUPPORTED, "the mailbox exchange does not carry the Ackermann constraint");
     return SMPC_OK;
   };
+  // a mode-1 exchange (furthest point) that timed out leaves the device-side state set: the
+  // mode-0 exchange of the same tick then publishes nothing and reports here
   auto p2p_check = [&]() -> int {
-    if (c->h_out[3 * T + 6] != 0.0f) return fail(c, SMPC_ERR_DEVICE, "shard exchange: a peer's tuple never arrived");
-    return SMPC_OK;
+    if (c->h_out[3 * T + 6] == 0.0f) return SMPC_OK;
+    c->p2p_failed = true;
+    c->hint_valid = false;
+    char msg[160];
+    snprintf(msg, sizeof(msg), "shard exchange %u: a peer's tuple did not arrive within %u ms", c->p2p_xseq,
+             c->p2p_timeout_ms);
+    return fail(c, SMPC_ERR_DEVICE, msg);
   };
   auto gather_combine_fetch = [&](const float* d_used) -> int {
     if (p2p) {

@@ -233,6 +233,10 @@ class Smpc:
         blob = b"".join(handles)
         self._ck(self.lib.smpc_shard_p2p_init(self.h, C.c_char_p(blob), rank, world))
 
+    def shard_p2p_set_timeout(self, milliseconds):
+        """Wall-clock bound of the in-kernel wait for the peers' tuples (default 10 000 ms)."""
+        self._ck(self.lib.smpc_shard_p2p_set_timeout(self.h, int(milliseconds)))
+
     def shard_tick(self, tick, u, speculate=True):
         """One batch-sharded tick, ncclAllGather / ncclAllReduce included (collective)."""
         u = np.ascontiguousarray(u, dtype=np.float32).copy()
@@ -264,15 +268,23 @@ class SmpcGroup:
         self.h = h
 
     def optimize(self, ticks, us):
-        """ticks, us: one per member; returns [(u_new, SmpcTickOut)] in member order.
-        Passing the same `ticks` list object again reuses its C structs."""
+        """ticks, us: one per member; returns [(u_new, SmpcTickOut)] in member order."""
         n = len(self.members)
-        if getattr(self, "_ticks", None) is not ticks:
-            self._ticks = ticks
-            self._ins = (A.SmpcTickIn * n)(*[t.c for t in ticks])
+        if getattr(self, "_ins", None) is None or len(ticks) != n:
+            if len(ticks) != n:
+                raise ValueError("one tick per member")
+            self._ins = (A.SmpcTickIn * n)()
+            self._src = [None] * n
             self._bufs = np.empty((n, 3, self.members[0].T), np.float32)
             self._ptrs = (C.c_void_p * n)(*[self._bufs[i].ctypes.data for i in range(n)])
             self._outs = (A.SmpcTickOut * n)()
+        for i, t in enumerate(ticks):
+            # Tick.c is rebuilt whenever a field of the tick was assigned: copy it again when
+            # it is not the struct object this slot was filled from (an identity check per member)
+            c = t.c
+            if self._src[i] is not c:
+                self._ins[i] = c
+                self._src[i] = c
         for i, u in enumerate(us):
             self._bufs[i] = u
         rc = self.lib.smpc_group_optimize(self.h, self._ins, self._ptrs, self._outs)

@@ -558,3 +558,25 @@ def test_non_holonomic_model_draws_no_vy_noise(Smpc, Oracle):
     assert not gy.any() and not oy.any()
     assert np.max(np.abs(gx - ox)) < 2e-6 and np.max(np.abs(gz - oz)) < 2e-6
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label="diffdrive rng")
+
+
+@pytest.mark.parametrize("model", ["Omni", "DiffDrive", "Ackermann"])
+def test_reference_smoke_fixture(Smpc, Oracle, model):
+    """test/optimizer_smoke_test.cpp:45-116 on the GPU: the reference's 40x40 costmap with the
+    8x8 block of cost 250 under the robot, batch 400, horizon 15, the three motion models with
+    their critic lists.  The reference's own assertion (no throw: the tick does not fail) plus
+    parity with the oracle on the same noise."""
+    from tests.helpers import reference_smoke_fixture
+    cfg, cells, res, tick, u0, cr = reference_smoke_fixture(model)
+    noise = make_noise(cfg.batch_size, cfg.time_steps)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        obj.set_critics(cr)
+        obj.set_costmap(cells, 0.0, 0.0, res, inscribed_radius=0.0, cost_scaling_factor=10.0,
+                        inflation_radius=0.55)
+        obj.set_noise(*noise)
+    ug, og = g.optimize(tick, u0)       # raises on any error of the C-ABI
+    uo, oo = o.optimize(tick, u0)
+    assert og.fail_flag == 0 and oo.fail_flag == 0
+    assert og.non_colliding == oo.non_colliding
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"reference smoke fixture {model}")

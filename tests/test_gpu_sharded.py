@@ -149,7 +149,7 @@ def test_mailbox_tick_single_rank():
 
 
 _MAILBOX_WORKER = r"""
-import os, sys
+import os, sys, traceback
 import numpy as np
 import torch.distributed as dist
 sys.path.insert(0, os.environ["SMPC_REPO"])
@@ -164,19 +164,33 @@ B, T = 8192, 40
 cfg, scn, noise = make_case(B, T)
 per = B // world
 a, b = rank * per, (rank + 1) * per
-sh = Smpc(default_config(batch_size=per, time_steps=T, shard_offset=a, global_batch_size=B))
-configure(sh, scn, noise=tuple(n[a:b] for n in noise))
-so = MailboxShardedOptimizer(sh, speculate=True)
+# everything a rank builds besides its shard comes BEFORE the exchange is set up: the ranks
+# enter tick 0 together (barrier below), so the in-kernel wait only has to cover one tick's skew
 ref = None
 if rank == 0:
     ref = Smpc(cfg)
     configure(ref, scn, noise=noise)
+sh = Smpc(default_config(batch_size=per, time_steps=T, shard_offset=a, global_batch_size=B))
+configure(sh, scn, noise=tuple(n[a:b] for n in noise))
+so = MailboxShardedOptimizer(sh, speculate=True)
+dist.barrier()
 u_s = u_r = scn.u0
 for k in range(5):
-    us, outs = so.optimize(scn.tick, u_s)
+    err, us, outs = None, None, None
+    try:
+        us, outs = so.optimize(scn.tick, u_s)
+    except Exception as e:
+        err = f"tick {k}: {e!r}"
+        print(f"MAILBOX_FAIL rank {rank} {err}", flush=True)
+    # the outcome of the tick is shared, so that every rank ends with its OWN message instead
+    # of a broken-pipe error of the rendezvous
     got = [None] * world
-    dist.all_gather_object(got, us.tobytes())
-    assert all(g == got[0] for g in got), "ranks disagree"
+    dist.all_gather_object(got, (err, None if us is None else us.tobytes()))
+    bad = [(r, e) for r, (e, _) in enumerate(got) if e]
+    if bad:
+        print(f"MAILBOX_ABORT rank {rank}: failed ranks {bad}", flush=True)
+        sys.exit(3)
+    assert all(g[1] == got[0][1] for g in got), f"tick {k}: ranks disagree"
     if rank == 0:
         ur, outr = ref.optimize(scn.tick, u_r)
         assert outs.furthest_reached_path_point == outr.furthest_reached_path_point, k
@@ -189,30 +203,127 @@ print("MAILBOX_OK", rank, flush=True)
 """
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_mailbox_tick_processes_on_one_gpu(tmp_path, world):
-    """Two and four ranks (processes sharing this GPU — the only multi-rank rehearsal a one-GPU
-    box allows) exchange their shard tuples through IPC-mapped mailboxes, no collective: all
-    end every tick with the same control sequence, which is the unsharded one.  Small batches,
-    so that the processes' kernels fit on the GPU side by side."""
+def _run_ranks(tmp_path, script_text, world, port, extra_env=None, timeout=240):
+    """Start `world` worker processes, wait for all of them, return [(returncode, output)]."""
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "mailbox_worker.py"
-    script.write_text(_MAILBOX_WORKER)
-    env = dict(os.environ, SMPC_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + world),
+    script = tmp_path / "worker.py"
+    script.write_text(script_text)
+    env = dict(os.environ, SMPC_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = []
+    res = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=240)
+            o, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
-            raise
-        outs.append(o)
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"MAILBOX_OK {r}" in o, o[-3000:]
+            o, _ = p.communicate()
+            o = (o or "") + "\n[killed: timeout]"
+        res.append((p.returncode, o or ""))
+    return res
+
+
+def _report(res):
+    """Every rank's return code and the tail of its output; the ranks whose failure is their own
+    (not the rendezvous breaking because a peer left) come first."""
+    def secondary(o):
+        return "Connection closed by peer" in o or "MAILBOX_ABORT" in o
+    order = sorted(range(len(res)), key=lambda r: (res[r][0] == 0, secondary(res[r][1])))
+    return "\n".join(f"---- rank {r}: rc={res[r][0]} ----\n{res[r][1][-2500:]}" for r in order)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mailbox_tick_processes_on_one_gpu(tmp_path, world):
+    """Two and four ranks as PROCESSES SHARING THIS GPU exchange their shard tuples through
+    IPC-mapped mailboxes, no collective: all end every tick with the same control sequence,
+    which is the unsharded one.
+
+    What this rehearsal proves: the IPC export / mapping of the mailboxes, cross-process
+    visibility of the system-scope stores and sequence words, the parity / sequence protocol
+    over several ticks (non-speculative first tick through mode 1 included) and the combine.
+    What it cannot prove: anything about xGMI (the peers' mailboxes are on the same device) or
+    about timing across GPUs.  It also leans on something real deployments do not need: the
+    waiting kernel of one process and the kernels of its peers must make progress side by side
+    on ONE device, which the hardware scheduler usually but not contractually provides — hence
+    small batches (the kernels fit next to each other) and the library's wall-clock bound on
+    the wait (a starved peer fails the tick after smpc_shard_p2p_set_timeout, it cannot hang
+    the GPU)."""
+    res = _run_ranks(tmp_path, _MAILBOX_WORKER, world, 29533 + world)
+    ok = all(rc == 0 and f"MAILBOX_OK {r}" in o for r, (rc, o) in enumerate(res))
+    assert ok, _report(res)
+
+
+_MAILBOX_LATE_WORKER = r"""
+import os, sys, time
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SMPC_REPO"])
+from mpcholonavigation_amd.optimizer import Smpc, SmpcError
+from mpcholonavigation_amd.sharded import MailboxShardedOptimizer
+from mpcholonavigation_amd.tick import default_config
+from tests.helpers import configure, make_case
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, T = 4096, 40
+cfg, scn, noise = make_case(B, T)
+per = B // world
+a, b = rank * per, (rank + 1) * per
+sh = Smpc(default_config(batch_size=per, time_steps=T, shard_offset=a, global_batch_size=B))
+configure(sh, scn, noise=tuple(n[a:b] for n in noise))
+so = MailboxShardedOptimizer(sh, speculate=True)
+sh.shard_p2p_set_timeout(300)
+dist.barrier()
+u, _ = so.optimize(scn.tick, scn.u0)          # tick 0: both ranks, fine
+dist.barrier()
+if rank == 1:
+    time.sleep(1.5)                            # rank 1 is late for tick 1, beyond rank 0's bound
+errs = []
+for k in (1, 2):
+    try:
+        so.optimize(scn.tick, u)
+        errs.append(None)
+    except SmpcError as e:
+        errs.append((e.code, str(e)))
+got = [None] * world
+dist.all_gather_object(got, errs)
+if rank == 0:
+    # rank 0 timed out at tick 1 (its tuple was already out), then refuses to tick at all
+    assert got[0][0] is not None and got[0][0][0] == -3 and "did not arrive" in got[0][0][1], got
+    assert got[0][1] is not None and got[0][1][0] == -4, got
+    # rank 1 either completed tick 1 with the tuple it had received and fails at tick 2 (rank 0
+    # is silent by then), or needed a second exchange in tick 1 (speculation miss) and failed there
+    if got[1][0] is None:
+        assert got[1][1] is not None and got[1][1][0] == -3, got
+    else:
+        assert got[1][0][0] == -3 and got[1][1][0] == -4, got
+# a collective re-init brings the exchange back
+so = MailboxShardedOptimizer(sh, speculate=True)
+sh.reset()
+configure(sh, scn, noise=tuple(n[a:b] for n in noise))
+dist.barrier()
+u2, _ = so.optimize(scn.tick, scn.u0)
+got = [None] * world
+dist.all_gather_object(got, u2.tobytes())
+assert all(g == got[0] for g in got)
+assert np.allclose(u2, u, rtol=0, atol=1e-6)
+dist.barrier()
+print("MAILBOX_OK", rank, flush=True)
+"""
+
+
+def test_mailbox_late_peer_fails_loudly_and_recovers(tmp_path):
+    """A peer that is later than the wait's bound: the waiting rank's tick fails with
+    SMPC_ERR_DEVICE (no hang), that rank then refuses further mailbox ticks (SMPC_ERR_STATE) and
+    stays silent, so the late rank — which still completed the tick with the tuple it had
+    received — fails at its NEXT exchange: within one tick every rank has an error in hand, and
+    a collective re-init (+ reset) restores the exchange.  Same one-GPU caveats as above."""
+    res = _run_ranks(tmp_path, _MAILBOX_LATE_WORKER, 2, 29541)
+    ok = all(rc == 0 and f"MAILBOX_OK {r}" in o for r, (rc, o) in enumerate(res))
+    assert ok, _report(res)

@@ -549,3 +549,31 @@ def test_defaults_match_reference_parameters(oracle_lib):
     assert bytes(p) == bytes(q)
     assert p.obstacles.collision_cost == 10000.0 and p.path_align.offset_from_furthest == 20
     assert p.path_follow.offset_from_furthest == 6 and abs(p.path_follow.threshold_to_consider - 1.4) < 1e-6
+
+
+@pytest.mark.parametrize("model", ["Omni", "DiffDrive", "Ackermann"])
+def test_optimizer_smoke_fixture_does_not_fail(model):
+    """test/optimizer_smoke_test.cpp:45-116 — the reference's only fixture that puts
+    ObstaclesCritic / CostCritic in front of a non-blank costmap (a block of cost 250 under the
+    robot).  Its assertion is EXPECT_NO_THROW(evalControl): the tick must not end with every
+    rollout colliding (fallback would throw after the retries, src/optimizer.cpp:166-183).  On
+    the restatement: fail_flag == 0, and the costs are finite and not all equal (the block IS
+    scored: 250 < 253 is not a collision but costs through the inflation formula)."""
+    import numpy as np
+    from oracle.loader import Oracle
+    from tests.helpers import reference_smoke_fixture
+    from mpcholonavigation_amd.synthetic import make_noise
+    cfg, cells, res, tick, u0, cr = reference_smoke_fixture(model)
+    o = Oracle(cfg)
+    o.set_critics(cr)
+    # Costmap2DROS's default plugin list carries an inflation layer (radius 0.55, scaling 10);
+    # the bow-tie ordering of getDummySquareFootprint puts an edge through the origin:
+    # inscribed radius 0
+    o.set_costmap(cells, 0.0, 0.0, res, inscribed_radius=0.0, cost_scaling_factor=10.0, inflation_radius=0.55)
+    o.set_noise(*make_noise(cfg.batch_size, cfg.time_steps))
+    u, out = o.optimize(tick, u0)
+    assert out.fail_flag == 0
+    assert out.non_colliding == cfg.batch_size      # cost 250 < 253: nobody collides
+    c = o.get_costs()
+    assert np.all(np.isfinite(c)) and np.all(np.isfinite(u))
+    assert float(c.max() - c.min()) > 0.0
