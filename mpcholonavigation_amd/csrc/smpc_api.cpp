@@ -644,6 +644,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
   // (setPathFurthestPointIfNotSet, utils.hpp:350-355)
   bool S_known = false, S_on_device = false;
   uint32_t S_host = 0;
+  float F_host = 0.f;
   const bool speculate = !(c->cfg.flags & SMPC_FLAG_NO_SPECULATION);
   for (uint32_t it = 0; it < c->cfg.iteration_count; ++it) {
     uint32_t flags = scoring_flags(c, fail_sticky);
@@ -684,11 +685,13 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
       fetched = true;
     }
     if (fetched && dF) {
-      S_host = static_cast<uint32_t>(c->h_out[iSused]);
+      F_host = c->h_out[iSused];
+      S_host = smpc_furthest_index(F_host);
       S_known = true;
     }
     if (spec_try) {
-      const uint32_t S_true = static_cast<uint32_t>(c->h_out[iS]);
+      F_host = c->h_out[iS];
+      const uint32_t S_true = smpc_furthest_index(F_host);
       S_host = S_true;
       S_known = true;
       if (S_true != hintS) {
@@ -719,10 +722,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     rc = fetch_out(c);
     if (rc != SMPC_OK) return rc;
   }
-  if (S_known) {
-    c->hint = S_host;
-    c->hint_valid = true;
-  }
+  if (S_known) remember_furthest(c, in, F_host);
   store_control_sequence(c, u_inout);
   if (out) {
     memset(out, 0, sizeof(*out));

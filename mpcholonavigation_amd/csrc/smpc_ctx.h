@@ -216,10 +216,17 @@ struct smpc_ctx {
   bool fail_in = false;
   uint32_t P = 0;
   uint32_t passes = 0;
-  // speculation on furthest_reached_path_point: last tick's value
+  // speculation on furthest_reached_path_point: the index this tick is scored with first
+  // (predict_hint: last tick's value carried forward by the robot's motion and the plan's shift)
   bool hint_valid = false;
   uint32_t hint = 0;
   uint64_t spec_misses = 0;
+  // what the prediction starts from: the last known F = index + fraction (smpc_dev.h) and the
+  // tick inputs it was measured on
+  float hint_F = 0.f;
+  bool anchor_valid = false;
+  double anchor_x = 0, anchor_y = 0;
+  std::vector<float> anchor_px, anchor_py;
   // completion polling on the host-mapped result (SMPC_NO_POLL=1 disables)
   bool poll_enabled = true;
   // Optimizer::isHolonomic (optimizer.cpp:235).  A non-holonomic model is the Omni data path
@@ -261,6 +268,10 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
 SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T);
 
 int check_tick(smpc_ctx* c, const smpc_tick_in* in);
+// the furthest point F (index + fraction) is now known for the tick inputs `in`: the next
+// prediction starts from here
+void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F);
+void predict_hint(smpc_ctx* c, const smpc_tick_in* in);
 int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in);
 
 int launch_furthest(smpc_ctx* c, float* d_furthest);

@@ -69,6 +69,7 @@ struct SmpcDev {
   uint32_t cost_t0;        // costmap cost under trajectory point 0 (same for every rollout)
   int32_t win_x0, win_y0, win_w, win_h;  // window staged in LDS (cells)
   float wxf, wyf;          // float images of the window corner (lane-per-rollout pass)
+  float cxf, cyf;          // ((x0, y0) - window corner) / resolution (lane-per-rollout pass)
   float cell_eps_w;        // guard band for the window-relative quotient
   float x00f, y00f;        // trajectory point 0 (identical for every rollout)
   const SmpcLut* lut;                     // [256]
@@ -130,6 +131,18 @@ struct SmpcDev {
   // developer aid (SMPC_LANE_TIMELINE=1): [gridDim.x][8] shader-clock stamps of the lane pass
   unsigned long long* timeline;
 };
+
+// The furthest reached path point travels as ONE float F = S + f: S the index (max over the
+// rollouts of the path point nearest to the rollout's endpoint, tools/utils.hpp:292-319) and
+// f in [-0.45, 0.45] how far the extreme rollout's endpoint sits from point S towards S + 1, in
+// segment lengths (0.5 would be the Voronoi edge where the nearest point flips).  max, the
+// exchange between GPUs and the float slot of the tuple work on F unchanged; every consumer of
+// the INDEX rounds.  The fraction only feeds the host's prediction of the next tick's index
+// (smpc_prepare.cpp predict_hint): a wrong prediction costs a re-score, never a wrong result.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+static inline uint32_t smpc_furthest_index(float F) {return (uint32_t)(F + 0.5f);}
 
 // optional finishing step of smpc_reduce_partials (single tuple -> new control sequence)
 struct SmpcFinal {

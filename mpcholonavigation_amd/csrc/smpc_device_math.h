@@ -68,7 +68,19 @@ __device__ __forceinline__ void smpc_sincos(float x, float& sn, float& cs)
 // |x| < 65536 only (the caller checks)
 __device__ __forceinline__ void smpc_sincos_fast(float x, float& sn, float& cs)
 {
+  // k = x / pi rounded to an integer, by adding 1.5 * 2^23 in the same fused multiply-add (the
+  // sum's unit in the last place is 1: the rounding of the fma IS the rounding to an integer,
+  // and the integer's parity is the sum's lowest mantissa bit) — one instruction instead of
+  // multiply, v_rndne and v_cvt_i32, which issue at half the rate of an fma (tools/ubench)
+#ifndef SMPC_X_MAGIC
+#define SMPC_X_MAGIC 1
+#endif
+#if SMPC_X_MAGIC
+  const float kf = fmaf(x, 0.31830987334251404f, 12582912.0f);
+  const float k = kf - 12582912.0f;
+#else
   const float k = rintf(x * 0.31830987334251404f);
+#endif
   float r = fmaf(-k, 3.1415927410125732f, x);
   r = fmaf(-k, -8.742277657347586e-08f, r);
   r = fmaf(-k, -3.4302490200117637e-15f, r);
@@ -81,7 +93,11 @@ __device__ __forceinline__ void smpc_sincos_fast(float x, float& sn, float& cs)
   pc = fmaf(pc, z, -1.38885692e-03f);
   pc = fmaf(pc, z, 4.16666558e-02f);
   const float c = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));
+#if SMPC_X_MAGIC
+  const uint32_t sign = __float_as_uint(kf) << 31;
+#else
   const uint32_t sign = (uint32_t)(int)k << 31;
+#endif
   sn = __uint_as_float(__float_as_uint(s) ^ sign);
   cs = __uint_as_float(__float_as_uint(c) ^ sign);
 }

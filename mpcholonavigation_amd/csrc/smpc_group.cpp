@@ -175,13 +175,14 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     int rc = fetch_out(c);
     if (rc != SMPC_OK) return rc;
     const bool need_f = (flags[i] & SD_NEED_FURTHEST) != 0;
-    const uint32_t S_true = static_cast<uint32_t>(c->h_out[3 * T + 2]);
+    const float F_true = c->h_out[3 * T + 2];
+    const uint32_t S_true = smpc_furthest_index(F_true);
     const bool miss = need_f && S_true != c->hint;
     const bool all_collide = (flags[i] & (SD_OBSTACLES | SD_COST)) && c->h_out[3 * T + 3] == 0.0f;
     if (miss || all_collide) {
       if (miss) {
         c->spec_misses++;
-        c->hint = S_true;   // smpc_optimize speculates with the true value now: one pass
+        remember_furthest(c, &ins[i], F_true);   // smpc_optimize speculates with the true value now: one pass
       }
       rc = single(i);
       if (rc != SMPC_OK) return rc;

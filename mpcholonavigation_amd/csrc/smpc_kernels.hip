@@ -137,7 +137,16 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// max over the parked endpoints of argmin_j |path_j - endpoint|^2 (first minimum wins)
+// max over the parked endpoints of argmin_j |path_j - endpoint|^2 (first minimum wins), as the
+// BITS of the float F = index + fraction (smpc_dev.h): F >= 0, so its bits order like the value
+__device__ __forceinline__ float furthest_fraction(float d_j, float d_next, float seg2)
+{
+  // the endpoint's coordinate along the segment from point j to j + 1, in segment lengths:
+  // (L^2 + d_j^2 - d_{j+1}^2) / (2 L^2); clamped so that the sum still rounds to j
+  const float t = seg2 > 0.f ? 0.5f + 0.5f * (d_j - d_next) / seg2 : 0.f;
+  return fminf(fmaxf(t, -0.45f), 0.45f);
+}
+
 __device__ __forceinline__ uint32_t flush_endpoint_ring(const float* ring_x, const float* ring_y,
                                                         uint32_t n, const float* s_px,
                                                         const float* s_py, uint32_t P, int lane)
@@ -157,7 +166,14 @@ __device__ __forceinline__ uint32_t flush_endpoint_ring(const float* ring_x, con
       bi = j;
     }
   }
-  uint32_t m = on ? bi : 0u;
+  float F = (float)bi;
+  if (bi + 1 < P) {
+    const float nx = s_px[bi + 1], ny = s_py[bi + 1];
+    const float sx = nx - s_px[bi], sy = ny - s_py[bi];
+    const float d_next = (nx - ex) * (nx - ex) + (ny - ey) * (ny - ey);
+    F = fmaxf(F + furthest_fraction(best, d_next, sx * sx + sy * sy), 0.f);
+  }
+  uint32_t m = on ? __float_as_uint(F) : 0u;
   m = max(m, dpp_u<0x111>(0u, m));
   m = max(m, dpp_u<0x112>(0u, m));
   m = max(m, dpp_u<0x114>(0u, m));
@@ -334,7 +350,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   float pa_inv_spacing = 0.f;   // (S-1) / D[S-1]: mean inverse spacing of the plan
   if (!FURTHEST_ONLY) {
     if (p.flags & SD_NEED_FURTHEST) {
-      S = p.d_furthest ? (uint32_t)(*p.d_furthest) : p.furthest_hint;
+      S = p.d_furthest ? smpc_furthest_index(*p.d_furthest) : p.furthest_hint;
       if (S >= p.P) S = p.P ? p.P - 1 : 0;
     }
     pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && p.pa_active[S] && S > 0;
@@ -949,14 +965,14 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   // ---- block combine -> one partial per block --------------------------------
   __syncthreads();
   if (FURTHEST_ONLY) {
-    // S_local >= 0 as float bits is order preserving
+    // S_local holds the bits of F >= 0: order preserving
     uint32_t* s_red = reinterpret_cast<uint32_t*>(smem + L.off_scr);
     if (lane == 0) s_red[wave] = S_local;
     __syncthreads();
     if (tid == 0) {
       uint32_t m = 0;
       for (int w = 0; w < nwave; ++w) m = max(m, s_red[w]);
-      atomicMax(p.furthest_out, __float_as_uint((float)m));
+      atomicMax(p.furthest_out, m);
     }
     return;
   }
@@ -965,7 +981,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   if (lane == 0) {
     myp[0] = m_run;
     myp[1] = s_run;
-    myp[2] = (float)S_local;
+    myp[2] = __uint_as_float(S_local);   // F = index + fraction (smpc_dev.h)
     myp[3] = (float)n_noncoll;
   }
 #pragma unroll

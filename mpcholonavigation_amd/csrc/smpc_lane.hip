@@ -35,10 +35,32 @@
 #define WAVE 64
 #define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
 
+// experiment switches (tools/variants.sh builds the library with some of them off)
+#ifndef LANE_X_GAMMA_N
+#define LANE_X_GAMMA_N 0     // gamma terms from the noise itself instead of c - u (measured: the noise
+                             // registers' longer life breaks the four-step prefetch, +35 % at 2 M rollouts)
+#endif
+#ifndef LANE_X_PFW_MIN
+#define LANE_X_PFW_MIN 1     // PreferForward as -dt sum min(vx, 0)
+#endif
+#ifndef LANE_X_CELL_AX
+#define LANE_X_CELL_AX 1     // cell index from the accumulated displacement (no double add per step)
+#endif
+#ifndef LANE_X_PIN_LDS
+#define LANE_X_PIN_LDS 0     // lookup pipeline as inline-asm LDS reads at the end of the step
+#endif
+#ifndef LANE_X_PARK_STEP
+#define LANE_X_PARK_STEP 0   // park the noised controls step by step instead of quad by quad
+#endif
+#ifndef LANE_X_CONST_VGPR
+#define LANE_X_CONST_VGPR 0  // the cell index's loop constants in vector registers
+#endif
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4))) * cfloat_p;
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LANE_PARK_STRIDE 68   // floats per time step of the LDS-parked control: 16-B aligned rows
                               // for ds_read_b128, 4-bank skew per lane (8 lanes cover the 32 banks)
 
@@ -321,7 +343,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   const double x0 = p.x0, y0 = p.y0;
   uint32_t S = 0;
   if (p.flags & SD_NEED_FURTHEST) {
-    S = p.d_furthest ? (uint32_t)(*p.d_furthest) : p.furthest_hint;
+    S = p.d_furthest ? smpc_furthest_index(*p.d_furthest) : p.furthest_hint;
     if (S >= p.P) S = p.P ? p.P - 1 : 0;
   }
   // the sentinels of s_D (every wave writes the same two values before its first read: no
@@ -346,7 +368,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   // ---- per-wave running softmax state; U[ctrl][t] lives in lane t ----------------
   float m_run = 3.0e38f, s_run = 0.f;
   float Ux = 0.f, Uy = 0.f, Uz = 0.f;
-  uint32_t S_local = 0, n_noncoll = 0;
+  float F_local = 0.f;   // furthest point of this wave's rollouts, index + fraction (smpc_dev.h)
+  uint32_t n_noncoll = 0;
 
   const uint32_t ngroups = (B + WAVE - 1) / WAVE;
   const uint32_t gw = blockIdx.x * nwave + wave;
@@ -382,18 +405,58 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     float yaw_max = 0.f;   // largest |yaw| seen (fast instance: range check of the sin/cos reduction)
     float alive = 1.0f;   // 1 until the rollout's first collision, then 0 (a float mask: fma(1, a, c) == c + a)
     // The costmap lookup is two dependent LDS reads (the cell's byte, then the byte's table
-    // entry) feeding an in-order accumulation.  It runs as a pipeline two steps deep: step t
-    // issues the byte read of its own cell, the table read for the byte of step t - 1, and
-    // accumulates the entry of step t - 2 — every read has a whole step to complete, nothing
-    // waits.  Primed with the all-zero table entry 256; drained after the loop.
+    // entry) feeding an in-order accumulation.  It runs as a pipeline two steps deep whose three
+    // stages all sit at the END of a step, behind one wait: accumulate the entry of step t - 2,
+    // issue the table read for the byte of step t - 1, issue the byte read of step t's own cell —
+    // every read has had a whole step to land, so the wait is free.  The reads are inline
+    // assembly (the wait too: the compiler's own waitcnt pass does not see them), which pins
+    // their place in the step; left to the scheduler the byte read sinks to just in front of
+    // its use and every step waits out an LDS round trip.  Primed with the all-zero table
+    // entry 256; drained after the loop.
     uint32_t cell_q = 256u;
-    SmpcLut e_q = {0.f, 0.f};
+    f32x2 e_q = {0.f, 0.f};   // {crit, rep} of SmpcLut
+    const uint32_t lds_lut = (uint32_t)(uintptr_t)s_lut, lds_map = (uint32_t)(uintptr_t)s_map;
+    auto lookup_wait = [&]() {   // both reads of the previous step have landed
+#if LANE_X_PIN_LDS
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cell_q), "+v"(e_q));
+#endif
+    };
+    auto lookup_accumulate = [&]() {
+      // steps after the first collision are never visited in the reference (masked)
+      alive = e_q.x < 0.f ? 0.f : alive;   // inCollision
+      crit = fmaf(alive, e_q.x, crit);
+      rep = fmaf(alive, e_q.y, rep);
+    };
+#if LANE_X_PIN_LDS
+    auto lookup_issue_entry = [&]() {          // e_q <- s_lut[cell_q]
+      const uint32_t a = lds_lut + (cell_q << 3);
+      asm volatile("ds_read_b64 %0, %1" : "=v"(e_q) : "v"(a));
+    };
+    auto lookup_issue_byte = [&](uint32_t idx) {   // cell_q <- s_map[idx]
+      const uint32_t a = lds_map + idx;
+      asm volatile("ds_read_u8 %0, %1" : "=v"(cell_q) : "v"(a));
+    };
+#else
+    auto lookup_issue_entry = [&]() {
+      const SmpcLut e = s_lut[cell_q];
+      e_q = f32x2{e.crit, e.rep};
+    };
+    auto lookup_issue_byte = [&](uint32_t idx) {cell_q = s_map[idx];};
+#endif
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     // PathAlign running state (path_align_critic.cpp:92-133)
     // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
     float traj_dist = 0.f, pa_sum = 0.f, pa_num = 0.f, sx_prev = p.x00f, sy_prev = p.y00f;
     uint32_t path_pt = 0;
 
+    // loop constants of the cell index, in vector registers: a scalar operand halves the issue
+    // rate of the instruction that reads it (tools/ubench)
+#if LANE_X_CONST_VGPR
+    const float k_rinv = in_vgpr(p.rinvf), k_cx = in_vgpr(p.cxf), k_cy = in_vgpr(p.cyf);
+#else
+    const float k_rinv = p.rinvf, k_cx = p.cxf, k_cy = p.cyf;
+#endif
+    const float k_edge = 0.5f - p.cell_eps_w;
     // one time step for the 64 rollouts of this wave; t, ux, uy, uz are wave-uniform
     // sample_slot: this step is a multiple of four (known at compile time in the unrolled quad)
     auto do_step = [&](const uint32_t t, const bool sample_slot, const float ux, const float uy, const float uz,
@@ -414,39 +477,45 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       const float dyr = vx * sn_prev + vy * cs_prev;
       ax = ax + dxr * dt;
       ay = ay + dyr * dt;
-      x = (float)(x0 + (double)ax);
-      y = (float)(y0 + (double)ay);
+      // The trajectory point itself, x = (float)(x0 + (double)ax) as the reference narrows it
+      // (optimizer.cpp:331-342), is formed only where its VALUE is consumed: at PathAlign's
+      // sample steps, at the endpoint and on the exact path of the cell index below.  The
+      // three double-precision instructions per axis run at half the rate of the plain float
+      // ones (tools/ubench: 4 against 2 SIMD cycles per wave64 instruction).
 
-      // ObstaclesCritic lookup (obstacles_critic.cpp:139-171).  Fast cell index first (see
-      // cost_at in smpc_device_math.h for the guard-band argument; the float origin is the
-      // LDS window's corner, so the truncated quotient is the window cell itself).  The
-      // rare lanes near a cell edge, outside the window or off the map get their LDS byte
-      // index from the exact path; then ONE pair of dependent LDS reads serves every lane
-      // and overlaps the sin/cos below.
+      // ObstaclesCritic lookup (obstacles_critic.cpp:139-171).  Fast cell index first: the
+      // window-relative quotient from the accumulated displacement in ONE fused multiply-add,
+      // q = ax / res + (x0 - window corner) / res.  Its distance to the quotient the reference
+      // truncates — ((double)x - origin) / res with x ROUNDED to float first — is bounded on the
+      // host (cell_eps_w: that rounding of x, the float images of the two constants, the fma's
+      // own rounding).  Lanes within that bound of a cell edge, outside the window or off the
+      // map get their LDS byte index from the exact path (the reference's own double arithmetic
+      // on the rounded x); then ONE pair of dependent LDS reads serves every lane and overlaps
+      // the sin/cos below.
+      uint32_t idx = 0;
       if (OBST) {
-        // entry of step t - 2: steps after the first collision are never visited in the
-        // reference (masked)
-        alive = e_q.crit < 0.f ? 0.f : alive;   // inCollision
-        crit = fmaf(alive, e_q.crit, crit);
-        rep = fmaf(alive, e_q.rep, rep);
-        e_q = s_lut[cell_q];                    // byte of step t - 1
+#if LANE_X_CELL_AX
+        const float qx = fmaf(ax, k_rinv, k_cx), qy = fmaf(ay, k_rinv, k_cy);
+#else
+        x = (float)(x0 + (double)ax);
+        y = (float)(y0 + (double)ay);
         const float qx = (x - p.wxf) * p.rinvf, qy = (y - p.wyf) * p.rinvf;
+#endif
         const float rx = __builtin_amdgcn_fractf(qx), ry = __builtin_amdgcn_fractf(qy);
         const int lx = cvt_floor_i32(qx), ly = cvt_floor_i32(qy);
         // guard band as ONE compare: both fractions at least eps away from a cell edge <=>
         // max(|rx - 1/2|, |ry - 1/2|) <= 1/2 - eps (a NaN fails it; the two extra float
-        // roundings, < 1e-7, sit inside the factor 2 the host puts on eps).  Three compares
-        // and two scalar ANDs per step instead of six and five: the wave's own serial issue is
-        // what bounds the pass.
+        // roundings, < 1e-7, sit inside the factor 2 the host puts on eps).
         const float edge = fmaxf(fabsf(rx - 0.5f), fabsf(ry - 0.5f));
-        const bool fast = (edge <= 0.5f - p.cell_eps_w) &
+        const bool fast = (edge <= k_edge) &
                           ((uint32_t)lx < (uint32_t)p.win_w) & ((uint32_t)ly < (uint32_t)p.win_h);
-        // window cells fit 24 bits: v_mad_u32_u24 (full rate) instead of a 64-bit multiply-add
-        uint32_t idx = __umul24((uint32_t)ly, (uint32_t)p.win_w) + (uint32_t)lx;   // (meaningless if !fast)
+        // window cells fit 24 bits: v_mad_u32_u24 instead of a 64-bit multiply-add
+        idx = __umul24((uint32_t)ly, (uint32_t)p.win_w) + (uint32_t)lx;   // (meaningless if !fast)
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0, 0)) {
-          if (!fast) idx = cell_byte_exact(p, s_map, x, y, (uint32_t)(wave * WAVE + lane));
+          if (!fast)
+            idx = cell_byte_exact(p, s_map, (float)(x0 + (double)ax), (float)(y0 + (double)ay),
+                                  (uint32_t)(wave * WAVE + lane));
         }
-        cell_q = s_map[idx];
       }
 
       // cos_[t+1] = cos(yaw[t]); the last step's is never used
@@ -456,18 +525,33 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         yaw_max = fmaxf(yaw_max, fabsf(yaw));
         smpc_sincos_fast(yaw, sn_prev, cs_prev);
       }
-      // PreferForwardCritic (prefer_forward_critic.cpp:42-46)
+      // PreferForwardCritic (prefer_forward_critic.cpp:42-46): sum_t max(-vx, 0) dt, here as
+      // -dt sum_t min(vx, 0) — the factor once per rollout instead of once per step
+#if LANE_X_PFW_MIN
+      pfw = pfw + fminf(vx, 0.f);
+#else
       pfw = fmaf(fmaxf(-vx, 0.f), dt, pfw);
-      // updateControlSequence gamma terms (optimizer.cpp:365-380): sum_t u (c - u)
+#endif
+      // updateControlSequence gamma terms (optimizer.cpp:365-380): sum_t u (c - u).  c - u is
+      // the noise up to the rounding of c = u + n (|c - u - n| <= ulp(c) / 2: a few 1e-8 on
+      // terms that gamma / sigma^2 scales to ~1e-7 of a cost): the noise itself is used
+#if LANE_X_GAMMA_N
+      gx = fmaf(ux, n0, gx);
+      gz = fmaf(uz, n2, gz);
+      gy = fmaf(uy, n1, gy);
+#else
       gx = fmaf(ux, cvx - ux, gx);
       gz = fmaf(uz, cwz - uz, gz);
       gy = fmaf(uy, cvy - uy, gy);
+#endif
 
       // PathAlignCritic sample (uniform in t): trajectory points step, 2 step, ...
       // (trajectory_point_step is 4 here, the reference's default — the host sends any other
       // value to the wave-per-rollout pass — so the sample steps are the first of every quad
       // but the very first: no per-step bookkeeping, no branch in the other three steps)
       if (sample_slot && pa_on && t != 0) {
+        x = (float)(x0 + (double)ax);
+        y = (float)(y0 + (double)ay);
         const float ddx = x - sx_prev, ddy = y - sy_prev;
         traj_dist += fast_sqrt(ddx * ddx + ddy * ddy);
         sx_prev = x;
@@ -510,6 +594,12 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         pa_num += q[2];                  // segment valid ? 1 : 0 (path_align_critic.cpp:119-127)
         pa_sum = fmaf(q[2], d, pa_sum);
       }
+      if (OBST) {   // the lookup pipeline's three stages (see above)
+        lookup_wait();
+        lookup_accumulate();       // entry of step t - 2
+        lookup_issue_entry();      // byte of step t - 1
+        lookup_issue_byte(idx);    // this step's cell
+      }
     };
 
     // noise, time-major: row t is a uniform base + this lane's offset; four steps in flight.
@@ -530,8 +620,10 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       for (int k = 0; k < 3; ++k) uq[3 * i + k] = ldu(k, i);
     }
     uint64_t clk = __builtin_amdgcn_s_memtime();
-    // four steps; returns their noised controls cq[3 i + ctrl]
-    auto run_quad = [&](const uint32_t q, float (&cq)[12]) {
+    // four steps; each parks its noised controls at once (LANE_X_PARK_STEP) or the quad returns
+    // them in cq[3 i + ctrl] for the caller to park
+    auto run_quad = [&](auto hi_c, const uint32_t q, float (&cq)[12]) {
+      constexpr bool HI = decltype(hi_c)::value;
       // The two waves of a SIMD do not share it evenly by themselves: the older one wins every
       // tie and finishes its groups ~25 % sooner (41 us against 51 us for two groups), then the
       // younger one runs alone.  Swapping their priorities every 2^15 shader clocks — by the clock,
@@ -564,6 +656,17 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
         if (FULL || t < T)
           do_step(t, i == 0, uc[3 * i], uc[3 * i + 1], uc[3 * i + 2], n0, n1, n2, cq[3 * i], cq[3 * i + 1],
                   cq[3 * i + 2]);
+#if LANE_X_PARK_STEP
+        // park this step's controls now: three values live per step instead of twelve per quad
+        if constexpr (HI) {
+          PX1[8 * i + (q - 8)] = cq[3 * i];
+          PY1[8 * i + (q - 8)] = cq[3 * i + 1];
+        } else {
+          PX0[8 * i + q] = cq[3 * i];
+          PY0[8 * i + q] = cq[3 * i + 1];
+        }
+        park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+#endif
       }
     };
     // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
@@ -571,36 +674,42 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
 #pragma unroll 2
     for (uint32_t q = 0; q < qh; ++q) {
       float cq[12];
-      run_quad(q, cq);
+      run_quad(std::false_type{}, q, cq);
+#if !LANE_X_PARK_STEP
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         PX0[8 * i + q] = cq[3 * i];
         PY0[8 * i + q] = cq[3 * i + 1];
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
+#endif
     }
 #pragma unroll 2
     for (uint32_t q = 8; q < nquad; ++q) {
       float cq[12];
-      run_quad(q, cq);
+      run_quad(std::true_type{}, q, cq);
+#if !LANE_X_PARK_STEP
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         PX1[8 * i + (q - 8)] = cq[3 * i];
         PY1[8 * i + (q - 8)] = cq[3 * i + 1];
         park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
       }
+#endif
     }
     if (OBST) {   // drain the lookup pipeline: the entries of the last two steps
-      alive = e_q.crit < 0.f ? 0.f : alive;
-      crit = fmaf(alive, e_q.crit, crit);
-      rep = fmaf(alive, e_q.rep, rep);
-      e_q = s_lut[cell_q];
-      alive = e_q.crit < 0.f ? 0.f : alive;
-      crit = fmaf(alive, e_q.crit, crit);
-      rep = fmaf(alive, e_q.rep, rep);
+      lookup_wait();
+      lookup_accumulate();
+      lookup_issue_entry();
+      lookup_wait();
+      lookup_accumulate();
     }
     // (a NaN yaw is sticky in the cumulative sum: the last one shows it)
     if (!SAFE && __builtin_expect(__any(!(yaw_max < 65536.0f) || !(fabsf(acc_yaw) < 65536.0f)), 0)) return true;
+
+    // the endpoint (trajectory point T - 1), as the reference narrows it
+    x = (float)(x0 + (double)ax);
+    y = (float)(y0 + (double)ay);
 
     // ================= per-rollout epilogue, lane = rollout ==============================
     // nearest path point of the endpoint (utils.hpp:292-319): first minimum wins
@@ -634,9 +743,20 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       float dd[4];
       block_d2(s_px + bj, s_py + bj, dd);
       const uint32_t bi = bj + (dd[0] == best ? 0u : dd[1] == best ? 1u : dd[2] == best ? 2u : dd[3] == best ? 3u : 0u);
-      uint32_t m = live ? bi : 0u;
-      for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, WAVE));
-      S_local = max(S_local, m);
+      // index + how far the endpoint sits towards the next point, in segment lengths (what the
+      // host predicts the next tick's index from; smpc_dev.h)
+      float F = (float)bi;
+      if (bi + 1 < p.P) {
+        const float nx = s_px[bi + 1], ny = s_py[bi + 1];
+        const float sgx = nx - s_px[bi], sgy = ny - s_py[bi];
+        const float d_next = (nx - x) * (nx - x) + (ny - y) * (ny - y);
+        const float seg2 = sgx * sgx + sgy * sgy;
+        const float tt = seg2 > 0.f ? 0.5f + 0.5f * (best - d_next) * fast_rcp(seg2) : 0.f;
+        F = fmaxf(F + fminf(fmaxf(tt, -0.45f), 0.45f), 0.f);
+      }
+      float m = live ? F : 0.f;
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+      F_local = fmaxf(F_local, m);
     }
     // costs (every cost_power == 1): the lean association of smpc_pass MODE 0
     float cost = (p.flags & SD_ACCUMULATE) ? p.costs_prev[bl] : 0.f;
@@ -651,7 +771,11 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       const float fdx = x - pf_x, fdy = y - pf_y;
       uni += p.pf_weight * fast_sqrt(fdx * fdx + fdy * fdy);
     }
+#if LANE_X_PFW_MIN
+    if (p.flags & SD_PREFER_FORWARD) lin += (pfw * -dt) * p.pfw_weight;
+#else
     if (p.flags & SD_PREFER_FORWARD) lin += pfw * p.pfw_weight;
+#endif
     lin += p.g_vx * gx;
     lin += p.g_wz * gz;
     lin += p.g_vy * gy;
@@ -731,7 +855,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   if (lane == 0) {
     myp[0] = m_run;
     myp[1] = s_run;
-    myp[2] = (float)S_local;
+    myp[2] = F_local;
     myp[3] = (float)n_noncoll;
   }
   if ((uint32_t)lane < T) {

@@ -109,6 +109,64 @@ static void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut, bool cons
   }
 }
 
+void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F)
+{
+  c->hint_F = F;
+  c->hint = smpc_furthest_index(F);
+  c->hint_valid = true;
+  c->anchor_x = in->pose_x;
+  c->anchor_y = in->pose_y;
+  c->anchor_px.assign(in->path_x, in->path_x + in->path_len);
+  c->anchor_py.assign(in->path_y, in->path_y + in->path_len);
+  c->anchor_valid = true;
+}
+
+// The index a tick is first scored with.  Between two ticks the robot advances and the plan
+// handed over by the controller is pruned to the robot (path_handler.cpp:48-143), so the
+// furthest reached path point of the last tick is stale by construction: at 0.3 m/s, 20 Hz
+// and 0.05 m between path points the index moves once every three ticks from the motion and
+// once every three ticks, the other way, from the pruning.  Both are known on the host: the
+// displacement of the pose along the plan at the furthest point, in segment lengths, and the
+// number of points the plan lost at its start (the old point the new first point coincides
+// with).  F' = F + displacement - shift, index = round(F').  Exactness never depends on this:
+// the scoring pass reports the true value and a miss is re-scored.
+void predict_hint(smpc_ctx* c, const smpc_tick_in* in)
+{
+  if (!c->hint_valid || !c->anchor_valid) return;
+  const uint32_t P0 = static_cast<uint32_t>(c->anchor_px.size()), P = in->path_len;
+  c->hint = smpc_furthest_index(c->hint_F);
+  if (P0 < 2 || P < 1) return;
+  const float* ox = c->anchor_px.data();
+  const float* oy = c->anchor_py.data();
+  auto d2 = [](float ax, float ay, float bx, float by) {return (ax - bx) * (ax - bx) + (ay - by) * (ay - by);};
+  // the old point the new plan starts at
+  uint32_t k = 0;
+  float best = std::numeric_limits<float>::max();
+  for (uint32_t j = 0; j < P0; ++j) {
+    const float d = d2(ox[j], oy[j], in->path_x[0], in->path_y[0]);
+    if (d < best) {
+      best = d;
+      k = j;
+    }
+  }
+  const uint32_t kn = k + 1 < P0 ? k + 1 : k - 1;
+  const float seg_k = d2(ox[k], oy[k], ox[kn], oy[kn]);
+  if (!(best <= 0.0625f * seg_k)) return;   // not a pruned copy of the old plan: nothing to carry over
+  uint32_t S0 = c->hint;
+  if (S0 >= P0) S0 = P0 - 1;
+  const uint32_t Sn = S0 + 1 < P0 ? S0 + 1 : S0 - 1;
+  const float sx = (S0 + 1 < P0 ? 1.f : -1.f) * (ox[Sn] - ox[S0]), sy = (S0 + 1 < P0 ? 1.f : -1.f) * (oy[Sn] - oy[S0]);
+  const float seg2 = sx * sx + sy * sy;
+  if (!(seg2 > 0.f)) return;
+  const float disp = static_cast<float>((in->pose_x - c->anchor_x) * sx + (in->pose_y - c->anchor_y) * sy) / seg2;
+  if (!(std::fabs(disp) < 4.f)) return;     // a jump, not a controller period's motion
+  const float Fp = c->hint_F + disp - static_cast<float>(k);
+  long h = std::lround(Fp);
+  if (h < 0) h = 0;
+  if (h > static_cast<long>(P) - 1) h = static_cast<long>(P) - 1;
+  c->hint = static_cast<uint32_t>(h);
+}
+
 int check_tick(smpc_ctx* c, const smpc_tick_in* in)
 {
   if (!c || !in) return SMPC_ERR_INVALID;
@@ -302,19 +360,28 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
     uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
     c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
-    // window-relative float cell index and its guard band (cost_at_lane)
+    // window-relative float cell index and its guard band.  The pass forms
+    //   q~ = fma(ax, (1/res)_f, cxf),   cxf = ((x0 - window corner) / res)_f
+    // from the accumulated displacement ax; the reference truncates
+    //   Q = ((double)x - origin) / res - win_x0,   x = (float)(x0 + (double)ax).
+    // |q~ - Q| is at most: the rounding of x to float, (1/2) ulp(|x|) / res with |x| inside the
+    // window (lanes outside it never take the fast path); three float roundings of quantities
+    // no larger than the window (the two constants' images and the fma's own); and the rounding
+    // of the window corner origin + win0 * res in double.
     const double rinv = 1.0 / c->map.res;
     const double wx = c->map.ox + static_cast<double>(d.win_x0) * c->map.res;
     const double wy = c->map.oy + static_cast<double>(d.win_y0) * c->map.res;
     d.wxf = static_cast<float>(wx);
     d.wyf = static_cast<float>(wy);
-    const double e_o = std::max(std::fabs(wx - static_cast<double>(d.wxf)),
-                                std::fabs(wy - static_cast<double>(d.wyf)));
-    // the reference divides (x - origin) by the resolution; the window corner is
-    // origin + win0 * res in double: one more rounding of that product and sum
+    d.cxf = static_cast<float>((in->pose_x - wx) * rinv);
+    d.cyf = static_cast<float>((in->pose_y - wy) * rinv);
+    const double ext_x = static_cast<double>(d.win_w + 1) * c->map.res, ext_y = static_cast<double>(d.win_h + 1) * c->map.res;
+    const double xmax = std::max(std::max(std::fabs(wx - c->map.res), std::fabs(wx + ext_x)),
+                                 std::max(std::fabs(wy - c->map.res), std::fabs(wy + ext_y)));
+    const double u24 = 5.9604644775390625e-08;   // 2^-24
     const double e_c = 2.3e-16 * (std::fabs(wx) + std::fabs(wy) + 1.0);
     const double qmax = static_cast<double>(std::max(d.win_w, d.win_h)) + 2.0;
-    const double eps = 2.0 * ((e_o + e_c) * rinv + 3.1 * 5.9604644775390625e-08 * qmax) + 1e-7;
+    const double eps = 2.0 * (u24 * xmax * rinv + 3.0 * u24 * qmax + e_c * rinv) + 1e-7;
     d.cell_eps_w = static_cast<float>(std::min(eps, 0.5));
   }
 
@@ -611,6 +678,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   rc = plan_launch(c, in, gates, nsamp, mode_now);
   if (rc != SMPC_OK) return rc;
 
+  predict_hint(c, in);
   c->gate_flags = gates;
   c->score_mode = mode_now;
   c->fail_in = in->fail_flag_in != 0;

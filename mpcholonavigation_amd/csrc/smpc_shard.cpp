@@ -95,7 +95,7 @@ int smpc_shard_combine(smpc_ctx* c, const float* d_tuples, uint32_t n_tuples, fl
     const bool obstacles_scored = (scoring_flags(c, c->fail_in) & (SD_OBSTACLES | SD_COST)) != 0;
     out->fail_flag = (c->fail_in || (obstacles_scored && c->h_out[3 * T + 3] == 0.0f)) ? 1 : 0;
     out->furthest_valid = (c->gate_flags & SD_NEED_FURTHEST) ? 1 : 0;
-    out->furthest_reached_path_point = static_cast<uint32_t>(c->h_out[3 * T + 2]);
+    out->furthest_reached_path_point = smpc_furthest_index(c->h_out[3 * T + 2]);
     out->non_colliding = static_cast<uint32_t>(c->h_out[3 * T + 3]);
     out->min_cost = c->h_out[3 * T + 0];
     out->sum_w = c->h_out[3 * T + 1];
@@ -304,7 +304,8 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
     rc = launch_score(c, flags, nullptr, nullptr, c->hint, c->d_tuple);
     if (rc == SMPC_OK) rc = gather_combine_fetch(nullptr);
     if (rc != SMPC_OK) return rc;
-    const uint32_t S_true = static_cast<uint32_t>(c->h_out[3 * T + 2]);
+    float F_true = c->h_out[3 * T + 2];
+    const uint32_t S_true = smpc_furthest_index(F_true);
     if (S_true != c->hint) {
       // miss: the gathered tuples carry the true batch-wide furthest point
       c->spec_misses++;
@@ -312,7 +313,9 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
       rc = launch_score(c, flags, nullptr, nullptr, S_true, c->d_tuple);
       if (rc == SMPC_OK) rc = gather_combine_fetch(nullptr);
       if (rc != SMPC_OK) return rc;
+      F_true = c->h_out[3 * T + 2];
     }
+    remember_furthest(c, in, F_true);
   } else {
     if (need_f) {
       rc = launch_furthest(c, c->d_furthest);
@@ -330,10 +333,7 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
     rc = launch_score(c, flags, nullptr, need_f ? c->d_furthest : nullptr, 0, c->d_tuple);
     if (rc == SMPC_OK) rc = gather_combine_fetch(need_f ? c->d_furthest : nullptr);
     if (rc != SMPC_OK) return rc;
-    if (need_f) {
-      c->hint = static_cast<uint32_t>(c->h_out[3 * T + 2]);
-      c->hint_valid = true;
-    }
+    if (need_f) remember_furthest(c, in, c->h_out[3 * T + 2]);
   }
   const bool obstacles_scored = (flags & (SD_OBSTACLES | SD_COST)) != 0;
   bool failed = c->fail_in;

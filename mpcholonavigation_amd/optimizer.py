@@ -16,7 +16,8 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmpc.so")
+# SMPC_LIB: developer override (kernel experiments build variants of the library side by side)
+LIB_PATH = os.environ.get("SMPC_LIB") or os.path.join(_HERE, "libsmpc.so")
 _lib = None
 
 

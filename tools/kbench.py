@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool: one-shot check of a kernel change — parity of the lane pass against the oracle
+on a small batch (costs, flips, Twist), then the scoring pass's duration (HIP events) and the
+tick's wall time at the bench sizes.  Needs a GPU.   python tools/kbench.py [tag]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mpcholonavigation_amd import _abi as A
+from bench import make_ctx, shift, algorithmic_bytes
+from tests.helpers import assert_parity, configure, make_case
+from mpcholonavigation_amd.optimizer import Smpc
+from oracle.loader import Oracle, build
+
+tag = sys.argv[1] if len(sys.argv) > 1 else ""
+build()
+for (B, T, M) in ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000)):
+    cfg, scn, noise = make_case(B, T, map_size=M)
+    cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert og.pass_kind == 1
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"{tag} {B}x{T} map {M}")
+    g.close()
+
+import torch
+for B in (262144, 2097152):
+    g, scn, cfg = make_ctx(B, 64, 200)
+    u = scn.u0
+    for _ in range(5):
+        un, out = g.optimize(scn.tick, u); u = shift(un)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    N = 60
+    for _ in range(N):
+        un, out = g.optimize(scn.tick, u); u = shift(un)
+    el = (time.perf_counter() - t0) / N
+    g.set_profile(True)
+    ps = []
+    for _ in range(40):
+        un, out = g.optimize(scn.tick, u); u = shift(un)
+        ps.append(out.score_pass_ms)
+    by = algorithmic_bytes(B, 64, 200, 200, 60)
+    p = float(np.median(ps))
+    print(f"[kbench {tag}] {B}x64: pass {p*1e3:.1f} us ({by/p/1e6/8000:.3f} of 8 TB/s), tick {el*1e6:.1f} us "
+          f"({by/el/1e9/8000:.3f}), passes/tick {out.passes}")
+    g.close()
