@@ -63,6 +63,10 @@ void free_ctx(smpc_ctx* c)
 
 int launch_furthest(smpc_ctx* c, float* d_furthest)
 {
+  {
+    const int rc = ensure_row_major(c);   // the wave-per-rollout pass reads the [B,T] tensors
+    if (rc != SMPC_OK) return rc;
+  }
   HIPCK(c, hipMemsetAsync(d_furthest, 0, sizeof(float), c->stream));
   SmpcDev d = c->dev;
   d.flags = c->gate_flags & SD_NEED_FURTHEST;
@@ -121,6 +125,8 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
     c->last_pass_kind = 1;
   } else {
     c->last_pass_kind = 0;
+    const int rc_rm = ensure_row_major(c);
+    if (rc_rm != SMPC_OK) return rc_rm;
     HIPCK(c, smpc_launch_pass(c->R, c->score_mode, d, c->lds, c->grid, pass_block(c->R), c->stream));
   }
   if (prof) {
@@ -227,10 +233,40 @@ int update_time_major(smpc_ctx* c)
   return SMPC_OK;
 }
 
+// the [B,T] tensors (wave-per-rollout pass, smpc_get_noise) from the time-major copy, when a
+// device-RNG draw filled only that one
+int ensure_row_major(smpc_ctx* c)
+{
+  if (c->rm_valid) return SMPC_OK;
+  const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
+  // [T][B] -> [B][T] is the same tiled transpose with the roles of the dimensions swapped
+  HIPCK(c, smpc_launch_transpose(c->d_tvx, c->d_nvx, T, B, c->stream));
+  if (c->holonomic) HIPCK(c, smpc_launch_transpose(c->d_tvy, c->d_nvy, T, B, c->stream));
+  HIPCK(c, smpc_launch_transpose(c->d_twz, c->d_nwz, T, B, c->stream));
+  c->rm_valid = true;
+  return SMPC_OK;
+}
+
 int draw_noise(smpc_ctx* c)
 {
   const uint64_t n = static_cast<uint64_t>(c->cfg.batch_size) * c->cfg.time_steps;
   const uint64_t base = c->cfg.shard_offset * c->cfg.time_steps;
+  if (c->use_tpr && (c->cfg.time_steps & 1u) == 0 && !getenv("SMPC_NO_FUSED_FILL")) {
+    // lane-per-rollout contexts: draw straight into the time-major layout that pass reads —
+    // one write of the noise instead of a write, a read and a second write (fill + transpose);
+    // the [B,T] copy is made only if something asks for it (ensure_row_major)
+    const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
+    HIPCK(c, smpc_launch_fill_noise_tm(c->d_tvx, B, T, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
+    HIPCK(c, smpc_launch_fill_noise_tm(c->d_twz, B, T, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
+    if (c->holonomic)
+      HIPCK(c, smpc_launch_fill_noise_tm(c->d_tvy, B, T, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
+    else
+      HIPCK(c, hipMemsetAsync(c->d_tvy, 0, n * sizeof(float), c->stream));
+    c->rm_valid = false;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->have_noise = true;
+    return SMPC_OK;
+  }
   // draw order vx, wz, vy (noise_generator.cpp:107-122)
   HIPCK(c, smpc_launch_fill_noise(c->d_nvx, n, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
   HIPCK(c, smpc_launch_fill_noise(c->d_nwz, n, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
@@ -241,6 +277,7 @@ int draw_noise(smpc_ctx* c)
   if (rc != SMPC_OK) return rc;
   HIPCK(c, hipStreamSynchronize(c->stream));
   c->have_noise = true;
+  c->rm_valid = true;
   return SMPC_OK;
 }
 }  // namespace smpc_impl
@@ -590,6 +627,7 @@ int smpc_set_noise(smpc_ctx* c, const float* nvx, const float* nvy, const float*
   }
   HIPCK(c, hipStreamSynchronize(c->stream));
   c->have_noise = true;
+  c->rm_valid = true;
   c->rng_mode = false;
   return SMPC_OK;
 }
@@ -619,6 +657,10 @@ int smpc_get_noise(smpc_ctx* c, float* nvx, float* nvy, float* nwz)
   if (!c->have_noise) return fail(c, SMPC_ERR_STATE, "no noise yet");
   HIPCK(c, hipSetDevice(c->device));
   const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
+  {
+    const int rc = ensure_row_major(c);
+    if (rc != SMPC_OK) return rc;
+  }
   HIPCK(c, hipStreamSynchronize(c->stream));
   if (nvx) HIPCK(c, hipMemcpy(nvx, c->d_nvx, n, hipMemcpyDeviceToHost));
   if (nvy) HIPCK(c, hipMemcpy(nvy, c->d_nvy, n, hipMemcpyDeviceToHost));

@@ -43,6 +43,8 @@ hipError_t smpc_launch_combine(const float* tuples, uint32_t G, uint32_t T, floa
                                float* host_out, uint32_t seq, hipStream_t st);
 hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
+hipError_t smpc_launch_fill_noise_tm(float* dst, uint32_t B, uint32_t T, uint64_t base, uint64_t seed,
+                                     uint32_t stream, uint32_t epoch, float sigma, hipStream_t st);
 hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float min_r, uint32_t seq,
                                  hipStream_t st);
 hipError_t smpc_launch_p2p_exchange(const float* my_tuple, const SmpcP2P& x, uint32_t T, int mode,
@@ -143,6 +145,8 @@ struct smpc_ctx {
   float* d_tvy = nullptr;       // one allocation, vy and wz follow vx
   float* d_twz = nullptr;
   bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
+  bool rm_valid = true;      // the [B,T] tensors hold the current noise (a device-RNG draw fills the
+                             // time-major copy only; ensure_row_major() makes the other on demand)
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
   uint32_t last_pass_kind = 0;
   // member of a smpc_group: the group uploads every member's tick block in one copy
@@ -288,6 +292,7 @@ float profile_pass_ms(smpc_ctx* c);
 uint32_t fail_only_flags(const smpc_ctx* c);
 uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky);
 int update_time_major(smpc_ctx* c);
+int ensure_row_major(smpc_ctx* c);
 int draw_noise(smpc_ctx* c);
 
 }  // namespace smpc_impl

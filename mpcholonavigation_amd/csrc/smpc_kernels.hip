@@ -19,6 +19,7 @@
 // reference's separate xtensor passes.
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "smpc_dev.h"
@@ -1396,6 +1397,32 @@ __global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, 
   }
 }
 
+// The same stream written TIME-MAJOR, dst[t * B + b] (the layout the lane-per-rollout pass
+// reads): thread (b, t pair) with b fastest, so a wave writes two coalesced 256-byte row pieces.
+// Element e = row0 * T + b * T + t of the global [B_global, T] tensor is the cos (e even) or sin
+// (e odd) half of Philox pair e / 2 exactly as in smpc_fill_noise; T must be even, so that a
+// pair never straddles two rollouts.
+__global__ void __launch_bounds__(256) smpc_fill_noise_tm(float* __restrict__ dst, uint32_t B, uint32_t T,
+                                                         uint64_t base, uint64_t seed, uint32_t stream,
+                                                         uint32_t epoch, float sigma)
+{
+  const uint64_t n = (uint64_t)B * (T >> 1);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = (uint32_t)(i % B), tp = (uint32_t)(i / B);
+    const uint64_t q = (base + (uint64_t)b * T + 2u * tp) >> 1;
+    uint32_t r0, r1;
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r0, r1);
+    const float u1 = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float radius = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.2831853071795864769f * u2;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    dst[(size_t)(2u * tp) * B + b] = radius * cs * sigma;
+    dst[(size_t)(2u * tp + 1u) * B + b] = radius * sn * sigma;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Self-test hook: the device sin/cos used by the rollout, evaluated on caller data.
 // ---------------------------------------------------------------------------
@@ -1543,6 +1570,16 @@ hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float 
 {
   hipLaunchKernelGGL(smpc_ackermann_constrain, dim3(1), dim3(256), 0, st, u_dev, u_host, T, min_r,
                      seq);
+  return hipGetLastError();
+}
+
+hipError_t smpc_launch_fill_noise_tm(float* dst, uint32_t B, uint32_t T, uint64_t base, uint64_t seed,
+                                     uint32_t stream, uint32_t epoch, float sigma, hipStream_t st)
+{
+  const uint64_t n = (uint64_t)B * (T >> 1);
+  uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+  if (grid == 0) grid = 1;
+  hipLaunchKernelGGL(smpc_fill_noise_tm, dim3(grid), dim3(256), 0, st, dst, B, T, base, seed, stream, epoch, sigma);
   return hipGetLastError();
 }
 

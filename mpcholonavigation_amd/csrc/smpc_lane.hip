@@ -67,12 +67,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------
 // [B][T] -> [T][B] (one-off, after the noise is drawn or supplied)
 // ---------------------------------------------------------------------------
+// SWAP: the tile index of the second dimension rides on blockIdx.x (the grid's x extent is the
+// one without a 65 535 limit: the larger dimension goes there)
+template <bool SWAP>
 __global__ void __launch_bounds__(256) smpc_transpose_bt(const float* __restrict__ src,
                                                         float* __restrict__ dst, uint32_t B,
                                                         uint32_t T)
 {
   __shared__ float tile[32][33];
-  const uint32_t bx = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+  const uint32_t bx = (SWAP ? blockIdx.y : blockIdx.x) * 32, ty0 = (SWAP ? blockIdx.x : blockIdx.y) * 32;
   const uint32_t lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
   for (uint32_t k = ly; k < 32; k += 8) {
     const uint32_t b = bx + k, t = ty0 + lx;
@@ -85,11 +88,15 @@ __global__ void __launch_bounds__(256) smpc_transpose_bt(const float* __restrict
   }
 }
 
+// src [B][T] -> dst [T][B]
 hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T,
                                  hipStream_t st)
 {
-  hipLaunchKernelGGL(smpc_transpose_bt, dim3((B + 31) / 32, (T + 31) / 32), dim3(256), 0, st, src,
-                     dst, B, T);
+  const uint32_t nb = (B + 31) / 32, nt = (T + 31) / 32;
+  if (nt > nb)
+    hipLaunchKernelGGL(smpc_transpose_bt<true>, dim3(nt, nb), dim3(256), 0, st, src, dst, B, T);
+  else
+    hipLaunchKernelGGL(smpc_transpose_bt<false>, dim3(nb, nt), dim3(256), 0, st, src, dst, B, T);
   return hipGetLastError();
 }
 

@@ -580,3 +580,37 @@ def test_reference_smoke_fixture(Smpc, Oracle, model):
     assert og.fail_flag == 0 and oo.fail_flag == 0
     assert og.non_colliding == oo.non_colliding
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"reference smoke fixture {model}")
+
+
+@pytest.mark.parametrize("B,T,off", [(70000, 64, 0), (65536, 40, 131072), (61441, 56, 7)])
+def test_fused_time_major_fill_is_the_same_stream(Smpc, monkeypatch, B, T, off):
+    """A lane-per-rollout context draws its device-RNG noise straight into the time-major layout
+    (smpc_fill_noise_tm) and makes the [B,T] copy only on demand: bit for bit the tensors of the
+    two-step path (fill [B,T], transpose), for a whole batch and for a shard of a larger one;
+    and the lane pass's tick on them equals the tick on the same tensors handed over through
+    smpc_set_noise."""
+    cfg = default_config(batch_size=B, time_steps=T, shard_offset=off, global_batch_size=off + B,
+                         flags=A.SMPC_FLAG_LANE_PER_ROLLOUT)
+    scn = make_scenario(T)
+    fused = Smpc(cfg)
+    configure(fused, scn)
+    fused.seed(99)
+    u_f, out_f = fused.optimize(scn.tick, scn.u0)
+    u_f2, out_f2 = fused.optimize(scn.tick, u_f)       # speculating tick: lane pass
+    assert out_f2.pass_kind == 1
+    monkeypatch.setenv("SMPC_NO_FUSED_FILL", "1")
+    plain = Smpc(cfg)
+    configure(plain, scn)
+    plain.seed(99)
+    for a, b in zip(fused.get_noise(), plain.get_noise()):
+        assert np.array_equal(a, b)
+    given = Smpc(cfg)
+    configure(given, scn, noise=fused.get_noise())
+    u_g, _ = given.optimize(scn.tick, scn.u0)
+    u_g2, out_g2 = given.optimize(scn.tick, u_g)
+    assert np.array_equal(u_f, u_g) and np.array_equal(u_f2, u_g2)
+    # a redraw moves to the next epoch on both paths alike
+    fused.redraw_noise()
+    plain.redraw_noise()
+    for a, b in zip(fused.get_noise(), plain.get_noise()):
+        assert np.array_equal(a, b)
