@@ -121,7 +121,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   // the lane-per-rollout pass scores with the full lean critic stack only
   if (c->lane_now && !(flags & SD_STORE_TRAJ)) {
     nblk = c->grid_tpr;
-    HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->stream));
+    HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->lane_rr, c->stream));
     c->last_pass_kind = 1;
   } else {
     c->last_pass_kind = 0;

@@ -54,9 +54,11 @@ hipError_t smpc_launch_p2p_exchange(const float* my_tuple, const SmpcP2P& x, uin
                                     hipStream_t st);
 
 hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
-hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st);
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, hipStream_t st);
 uint32_t smpc_lane_block();
+uint32_t smpc_lane_block_rr();
 hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu);
+hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_per_cu);
 hipError_t smpc_lane_set_lds_limit(int bytes);
 hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
 hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
@@ -88,7 +90,7 @@ const RcclApi* rccl();   // smpc_shard.cpp; null when RCCL cannot be loaded
 // partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
 inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
 constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
-constexpr uint32_t kLaneMaxT = 64;        // it parks 3 x 64 noised controls per lane in registers
+constexpr uint32_t kLaneMaxT = 128;       // T <= 64: 3 x 64 noised controls parked per lane (or re-read); T <= 128: re-read
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
                                            // 0.05 m around the robot; the rest is read from HBM/L2
@@ -148,6 +150,7 @@ struct smpc_ctx {
   bool rm_valid = true;      // the [B,T] tensors hold the current noise (a device-RNG draw fills the
                              // time-major copy only; ensure_row_major() makes the other on demand)
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
+  bool lane_rr = false;      // ... in its re-read form (no parked controls; T > 64 or SMPC_LANE_REREAD=1)
   uint32_t last_pass_kind = 0;
   // member of a smpc_group: the group uploads every member's tick block in one copy
   bool defer_upload = false;
@@ -269,7 +272,7 @@ TickLayout tick_layout(uint32_t T, uint32_t P);
 // LDS carve-up of the streaming pass.  nsamp = PathAlign samples per rollout (0: off).
 SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
                  uint32_t nsamp = 0);
-SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T);
+SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T, bool rr = false);
 
 int check_tick(smpc_ctx* c, const smpc_tick_in* in);
 // the furthest point F (index + fraction) is now known for the tick inputs `in`: the next

@@ -34,6 +34,7 @@
 
 #define WAVE 64
 #define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
+#define LANE_BLOCK_RR 256   // the re-read instances: 4 waves, three blocks per CU
 
 // experiment switches (tools/variants.sh builds the library with some of them off)
 #ifndef LANE_X_GAMMA_N
@@ -236,13 +237,22 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // ---------------------------------------------------------------------------
 // The pass
 // ---------------------------------------------------------------------------
-// FULL: T == 64, every parked register is written by every group; OBST: ObstaclesCritic scored
+// FULL: T == 64 NCH, every step slot of the unrolled loops is live; OBST: ObstaclesCritic scored
 // MANY: several planning instances in one launch (smpc_group_optimize): blockIdx.y picks
 // the instance, whose parameter block comes from device memory instead of the kernel arguments
-template <bool FULL, bool OBST, bool MANY>
-__global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0, const SmpcLds L,
-                                                                const SmpcDev* __restrict__ many)
+// NCH: horizon in chunks of 64 steps (T <= 64 NCH)
+// RR ("re-read"): the noised controls are NOT parked.  Once a group's weights are known the wave
+// reads the group's noise a second time — 64 steps of one control at a time, straight into the
+// registers the transpose-reduce consumes — and forms c = u + n again (the same single rounding).
+// The second read comes seconds of microseconds after the first: from the Infinity Cache, not
+// from HBM.  Without the 128 parked registers and the per-wave LDS slot a lane needs ~1/2 of
+// the register file's per-wave share: 256-thread blocks, three per CU (three waves per SIMD).
+// The only form for T > 64 (3 T parked values per lane do not fit any register budget).
+template <bool FULL, bool OBST, bool MANY, int NCH, bool RR>
+__global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, RR ? 3 : 1)
+smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ many)
 {
+  static_assert(RR || NCH == 1, "parked controls: one chunk of 64 steps");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
@@ -255,6 +265,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   // PathAlign's view of the path: {x, y, segment valid ? 1 : 0, 0} per point, one 16-byte read
   f32x4* s_pts4 = reinterpret_cast<f32x4*>(smem + L.off_pts4);
 
+  constexpr int BLK = RR ? LANE_BLOCK_RR : LANE_BLOCK;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,11 +292,11 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       const int ry = i / w4, rx = i - ry * w4;
       return reinterpret_cast<const uint32_t*>(p.map + (size_t)(p.win_y0 + ry) * p.W + p.win_x0)[rx];
     };
-    constexpr int kAhead = 5;   // 96 x 96 bytes / 4 / 512 threads
+    constexpr int kAhead = 96 * 96 / 4 / BLK + 1;   // a 96 x 96 window in one sweep of the block
     uint32_t tmp[kAhead];
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
-      const int i = tid + k * LANE_BLOCK;
+      const int i = tid + k * BLK;
       tmp[k] = i < n4 ? word(i) : 0u;
     }
     const SmpcLut lut_e = (OBST && tid < 256) ? p.lut[tid] : SmpcLut{0.f, 0.f};
@@ -297,10 +308,10 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     if (OBST) {
 #pragma unroll
       for (int k = 0; k < kAhead; ++k) {
-        const int i = tid + k * LANE_BLOCK;
+        const int i = tid + k * BLK;
         if (i < n4) reinterpret_cast<uint32_t*>(s_map)[i] = tmp[k];
       }
-      for (int i = tid + kAhead * LANE_BLOCK; i < n4; i += LANE_BLOCK)
+      for (int i = tid + kAhead * BLK; i < n4; i += BLK)
         reinterpret_cast<uint32_t*>(s_map)[i] = word(i);
       if (!vec) {
         for (int i = tid; i < ww * wh; i += blockDim.x) {
@@ -308,7 +319,8 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
           s_map[i] = p.map[(size_t)(p.win_y0 + ry) * p.W + p.win_x0 + rx];
         }
       }
-      if (tid < 257) const_cast<SmpcLut*>(s_lut)[tid] = lut_e;   // [256] is the all-zero entry
+      if (tid < 256) const_cast<SmpcLut*>(s_lut)[tid] = lut_e;
+      if (tid == 0) const_cast<SmpcLut*>(s_lut)[256] = SmpcLut{0.f, 0.f};   // the all-zero entry
       // one byte behind the window answers "off the map" (NO_INFORMATION,
       // obstacles_critic.cpp:209-212); behind it one byte per lane of every wave for costs
       // fetched from the global map (cells outside the window)
@@ -321,7 +333,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
       if (seg_on) s_D[tid] = g_D;
       s_pts4[tid] = f32x4{g_px, g_py, g_valid ? 1.0f : 0.f, 0.f};
     }
-    for (uint32_t i = tid + LANE_BLOCK; i < p.P; i += LANE_BLOCK) {   // paths beyond 512 points
+    for (uint32_t i = tid + BLK; i < p.P; i += BLK) {   // paths beyond one point per thread
       const float qx = p.px[i], qy = p.py[i];
       const bool seg = i + 1 < p.P;
       s_px[i] = qx;
@@ -337,7 +349,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   // u and the path are inputs of the launch: read them through the constant address space,
   // so that uniform loads stay scalar loads although the kernel also stores to global memory
   const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
-  const uint32_t T = FULL ? 64u : p.T, B = p.B;
+  const uint32_t T = FULL ? 64u * NCH : p.T, B = p.B;
   // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
   // three tensors, the lane's own offset (b * 4) is the vector offset
   // (the host lays the three [T,B] tensors out back to back: ONE descriptor, four scalar
@@ -374,7 +386,9 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
 
   // ---- per-wave running softmax state; U[ctrl][t] lives in lane t ----------------
   float m_run = 3.0e38f, s_run = 0.f;
-  float Ux = 0.f, Uy = 0.f, Uz = 0.f;
+  float Ux[NCH], Uy[NCH], Uz[NCH];   // chunk h: steps [64 h, 64 h + 64)
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) Ux[h] = Uy[h] = Uz[h] = 0.f;
   float F_local = 0.f;   // furthest point of this wave's rollouts, index + fraction (smpc_dev.h)
   uint32_t n_noncoll = 0;
 
@@ -401,7 +415,7 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     // index with the same scalar q' (the constant 8 i folds into the base register) and can
     // share one s_set_gpr_idx_on/off pair.
     f32x32 PX0, PX1, PY0, PY1;
-    if (!FULL) PX0 = PX1 = PY0 = PY1 = (f32x32)(0.f);
+    if (!FULL && !RR) PX0 = PX1 = PY0 = PY1 = (f32x32)(0.f);
 
     // ================= rollout + per-step critics, lane = rollout =====================
     float cpx = p.svx, cpy = p.svy, cpz = p.swz;   // v[:,0] = measured speed, v[:,t] = c[:,t-1]
@@ -665,44 +679,54 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
                   cq[3 * i + 2]);
 #if LANE_X_PARK_STEP
         // park this step's controls now: three values live per step instead of twelve per quad
-        if constexpr (HI) {
+        if constexpr (RR) {
+        } else if constexpr (HI) {
           PX1[8 * i + (q - 8)] = cq[3 * i];
           PY1[8 * i + (q - 8)] = cq[3 * i + 1];
         } else {
           PX0[8 * i + q] = cq[3 * i];
           PY0[8 * i + q] = cq[3 * i + 1];
         }
-        park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+        if constexpr (!RR) park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
 #endif
       }
     };
-    // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
-    const uint32_t qh = nquad < 8u ? nquad : 8u;
+    if constexpr (RR) {
+      // nothing is parked: the controls are formed again from the noise once the weights are known
 #pragma unroll 2
-    for (uint32_t q = 0; q < qh; ++q) {
-      float cq[12];
-      run_quad(std::false_type{}, q, cq);
+      for (uint32_t q = 0; q < nquad; ++q) {
+        float cq[12];
+        run_quad(std::false_type{}, q, cq);
+      }
+    } else {
+      // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
+      const uint32_t qh = nquad < 8u ? nquad : 8u;
+#pragma unroll 2
+      for (uint32_t q = 0; q < qh; ++q) {
+        float cq[12];
+        run_quad(std::false_type{}, q, cq);
 #if !LANE_X_PARK_STEP
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        PX0[8 * i + q] = cq[3 * i];
-        PY0[8 * i + q] = cq[3 * i + 1];
-        park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
-      }
+        for (int i = 0; i < 4; ++i) {
+          PX0[8 * i + q] = cq[3 * i];
+          PY0[8 * i + q] = cq[3 * i + 1];
+          park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+        }
 #endif
-    }
+      }
 #pragma unroll 2
-    for (uint32_t q = 8; q < nquad; ++q) {
-      float cq[12];
-      run_quad(std::true_type{}, q, cq);
+      for (uint32_t q = 8; q < nquad; ++q) {
+        float cq[12];
+        run_quad(std::true_type{}, q, cq);
 #if !LANE_X_PARK_STEP
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        PX1[8 * i + (q - 8)] = cq[3 * i];
-        PY1[8 * i + (q - 8)] = cq[3 * i + 1];
-        park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
-      }
+        for (int i = 0; i < 4; ++i) {
+          PX1[8 * i + (q - 8)] = cq[3 * i];
+          PY1[8 * i + (q - 8)] = cq[3 * i + 1];
+          park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+        }
 #endif
+      }
     }
     if (OBST) {   // drain the lookup pipeline: the entries of the last two steps
       lookup_wait();
@@ -806,41 +830,68 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
 
     // ================= U[t] += sum_b w_b c[b][t]: transpose-reduce in registers ==========
     const LaneW lw = lane_weights(w, lane);
-    {
-      float V[64];
+    if constexpr (RR) {
+      // the group's noise again (it was read within the last tens of microseconds: served on
+      // die), 64 steps of one control at a time, and c = u + n with the rounding of the step
 #pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        V[t] = PX0[8 * (t & 3) + (t >> 2)];
-        V[32 + t] = PX1[8 * (t & 3) + (t >> 2)];
-      }
-      Ux = fmaf(Ux, f, lane_reduce64(V, lw, lane));
+      for (int h = 0; h < NCH; ++h) {
 #pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        V[t] = PY0[8 * (t & 3) + (t >> 2)];
-        V[32 + t] = PY1[8 * (t & 3) + (t >> 2)];
-      }
-      Uy = fmaf(Uy, f, lane_reduce64(V, lw, lane));
-    }
-    {
-      // wz from the LDS slot: lane t walks its row of 64 rollouts
-      s_w[lane] = w;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const f32x4* row = reinterpret_cast<const f32x4*>(park + lane * LANE_PARK_STRIDE);
-      float acc0 = 0.f, acc1 = 0.f;
+        for (int ctrl = 0; ctrl < 3; ++ctrl) {
+          // all 64 loads go out before the first use (left alone the scheduler pairs every load
+          // with its add and waits for each in turn: 192 memory round trips per group)
+          float V[64];
 #pragma unroll
-      for (int bq = 0; bq < 16; bq += 2) {
-        const f32x4 w0 = reinterpret_cast<const f32x4*>(s_w)[bq], c0 = row[bq];
-        const f32x4 w1 = reinterpret_cast<const f32x4*>(s_w)[bq + 1], c1 = row[bq + 1];
+          for (int t = 0; t < 64; ++t) V[t] = ld(ctrl, 64u * h + t);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc0 = fmaf(w0[e], c0[e], acc0);
-          acc1 = fmaf(w1[e], c1[e], acc1);
+          for (int t = 0; t < 64; ++t) {
+            const uint32_t tt = 64u * h + t;
+            const float c = ldu(ctrl, tt) + V[t];
+            V[t] = (FULL || tt < T) ? c : 0.f;
+          }
+          const float r = lane_reduce64(V, lw, lane);
+          if (ctrl == 0) Ux[h] = fmaf(Ux[h], f, r);
+          else if (ctrl == 1) Uy[h] = fmaf(Uy[h], f, r);
+          else Uz[h] = fmaf(Uz[h], f, r);
         }
       }
-      Uz = fmaf(Uz, f, acc0 + acc1);
-      __builtin_amdgcn_wave_barrier();
+    } else {
+      {
+        float V[64];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+          V[t] = PX0[8 * (t & 3) + (t >> 2)];
+          V[32 + t] = PX1[8 * (t & 3) + (t >> 2)];
+        }
+        Ux[0] = fmaf(Ux[0], f, lane_reduce64(V, lw, lane));
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+          V[t] = PY0[8 * (t & 3) + (t >> 2)];
+          V[32 + t] = PY1[8 * (t & 3) + (t >> 2)];
+        }
+        Uy[0] = fmaf(Uy[0], f, lane_reduce64(V, lw, lane));
+      }
+      {
+        // wz from the LDS slot: lane t walks its row of 64 rollouts
+        s_w[lane] = w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const f32x4* row = reinterpret_cast<const f32x4*>(park + lane * LANE_PARK_STRIDE);
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int bq = 0; bq < 16; bq += 2) {
+          const f32x4 w0 = reinterpret_cast<const f32x4*>(s_w)[bq], c0 = row[bq];
+          const f32x4 w1 = reinterpret_cast<const f32x4*>(s_w)[bq + 1], c1 = row[bq + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = fmaf(w0[e], c0[e], acc0);
+            acc1 = fmaf(w1[e], c1[e], acc1);
+          }
+        }
+        Uz[0] = fmaf(Uz[0], f, acc0 + acc1);
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     return false;
   };
@@ -865,10 +916,14 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
     myp[2] = F_local;
     myp[3] = (float)n_noncoll;
   }
-  if ((uint32_t)lane < T) {
-    myp[4 + lane] = Ux;
-    myp[4 + T + lane] = Uy;
-    myp[4 + 2 * T + lane] = Uz;
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    const uint32_t tt = 64u * h + (uint32_t)lane;
+    if (tt < T) {
+      myp[4 + tt] = Ux[h];
+      myp[4 + T + tt] = Uy[h];
+      myp[4 + 2 * T + tt] = Uz[h];
+    }
   }
   __syncthreads();
   const float* allp = reinterpret_cast<const float*>(smem + L.off_scr);
@@ -895,11 +950,25 @@ __global__ void __launch_bounds__(LANE_BLOCK, 1) smpc_pass_lane(const SmpcDev p0
   stamp(6);
 }
 
-hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, hipStream_t st)
+// rr: the re-read instances (no parked controls; required for T > 64; ObstaclesCritic scored)
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, hipStream_t st)
 {
-  const bool full = p.T == 64u, obst = (p.flags & SD_OBSTACLES) != 0;
+  const bool obst = (p.flags & SD_OBSTACLES) != 0;
+  if (rr) {
+    // whole chunks only (T = 64 or 128): the ragged instances spill registers, and a spill in
+    // the time loop costs the noise prefetch its depth (every scratch access waits vmcnt(0))
+    if (!obst || (p.T != 64u && p.T != 128u)) return hipErrorInvalidValue;
+#define SMPC_LANE_LAUNCH_RR(N) \
+  hipLaunchKernelGGL((smpc_pass_lane<true, true, false, N, true>), dim3(grid), dim3(LANE_BLOCK_RR), L.total, st, p, L, \
+                     static_cast<const SmpcDev*>(nullptr))
+    if (p.T > 64u) SMPC_LANE_LAUNCH_RR(2);
+    else SMPC_LANE_LAUNCH_RR(1);
+#undef SMPC_LANE_LAUNCH_RR
+    return hipGetLastError();
+  }
+  const bool full = p.T == 64u;
 #define SMPC_LANE_LAUNCH(F, O) \
-  hipLaunchKernelGGL((smpc_pass_lane<F, O, false>), dim3(grid), dim3(LANE_BLOCK), L.total, st, p, L, \
+  hipLaunchKernelGGL((smpc_pass_lane<F, O, false, 1, false>), dim3(grid), dim3(LANE_BLOCK), L.total, st, p, L, \
                      static_cast<const SmpcDev*>(nullptr))
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
@@ -916,7 +985,7 @@ hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool fu
 {
   const SmpcDev none{};
 #define SMPC_LANE_LAUNCH(F, O) \
-  hipLaunchKernelGGL((smpc_pass_lane<F, O, true>), dim3(grid, n), dim3(LANE_BLOCK), L.total, st, none, L, \
+  hipLaunchKernelGGL((smpc_pass_lane<F, O, true, 1, false>), dim3(grid, n), dim3(LANE_BLOCK), L.total, st, none, L, \
                      d_many)
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
@@ -927,18 +996,21 @@ hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool fu
 }
 
 uint32_t smpc_lane_block() {return LANE_BLOCK;}
+uint32_t smpc_lane_block_rr() {return LANE_BLOCK_RR;}
 
-static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY
+static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8, 9: re-read with one, two chunks
 {
-  switch (k & 7) {
-    case 0: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, false>);
-    case 1: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, false>);
-    case 2: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false>);
-    case 3: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false>);
-    case 4: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, true>);
-    case 5: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, true>);
-    case 6: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, true>);
-    default: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, true>);
+  switch (k & 15) {
+    case 0: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, false, 1, false>);
+    case 1: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, false, 1, false>);
+    case 2: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false>);
+    case 3: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false>);
+    case 4: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, true, 1, false>);
+    case 5: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, true, 1, false>);
+    case 6: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, true, 1, false>);
+    case 7: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, true, 1, false>);
+    case 8: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, true>);
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 2, true>);
   }
 }
 
@@ -948,10 +1020,16 @@ hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu
                                                       LANE_BLOCK, lds_bytes);
 }
 
+hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_per_cu)
+{
+  const int k = T > 64u ? 9 : 8;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lane_kernel(k), LANE_BLOCK_RR, lds_bytes);
+}
+
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 8 && e == hipSuccess; ++k)
+  for (int k = 0; k < 10 && e == hipSuccess; ++k)
     e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }

@@ -56,15 +56,16 @@ SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, 
 }
 
 // LDS layout of the lane-per-rollout pass: window + the NO_INFORMATION byte + one scratch byte
-// per lane (cell_byte_exact), LUT, path, per wave the parked wz [64][68] + weights [64]
-SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T)
+// per lane (cell_byte_exact), LUT, path, per wave the parked wz [64][68] + weights [64]; the
+// re-read form parks nothing (per wave only the block combine's tuple)
+SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T, bool rr)
 {
-  const uint32_t lblock = smpc_lane_block();
+  const uint32_t lblock = rr ? smpc_lane_block_rr() : smpc_lane_block();
   SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
                         window_bytes != 0, 0);
   Lt.off_pts4 = Lt.off_scr;
   Lt.off_scr += align_up(std::max(P, 1u) * 16, 16);
-  Lt.scr_stride = align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);
+  Lt.scr_stride = rr ? align_up(4u + 3u * T, 4) : align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);
   Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
   return Lt;
 }
@@ -342,20 +343,29 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   // the lane pass samples PathAlign's trajectory points at the first step of every quad:
   // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
   if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
+  // the re-read form (no parked controls): the only one for T > 64; instances exist with
+  // ObstaclesCritic scored.  SMPC_LANE_REREAD=1 selects it for T <= 64 too (experiments).
+  const char* e_rr = getenv("SMPC_LANE_REREAD");
+  const bool force_rr = e_rr != nullptr && atoi(e_rr) != 0;
+  c->lane_rr = (T > 64 || force_rr) && (gates & SD_OBSTACLES) != 0 && (T == 64 || T == 128);
+  if (T > 64 && !c->lane_rr) c->lane_now = false;
   if (c->lane_now) {
-    const SmpcLds Lt = lane_lds(window_bytes, P, T);
+    const SmpcLds Lt = lane_lds(window_bytes, P, T, c->lane_rr);
     c->lane_window_bytes = window_bytes;
     c->lds_tpr = Lt;
     if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
   }
   if (c->lane_now) {
-    const uint32_t lblock = smpc_lane_block();
+    const uint32_t lblock = c->lane_rr ? smpc_lane_block_rr() : smpc_lane_block();
     const SmpcLds& Lt = c->lds_tpr;
-    if (c->occ_tpr_lds != Lt.total) {
+    const uint32_t occ_key = Lt.total ^ (c->lane_rr ? 0x80000000u : 0u);
+    if (c->occ_tpr_lds != occ_key) {
       int nb = 0;
-      if (smpc_lane_occupancy(T == 64, Lt.total, &nb) != hipSuccess || nb < 1) nb = 1;
+      const hipError_t e = c->lane_rr ? smpc_lane_occupancy_rr(T, Lt.total, &nb) : smpc_lane_occupancy(T == 64, Lt.total, &nb);
+      if (e != hipSuccess || nb < 1) nb = 1;
+      if (c->lane_rr && nb > 3) nb = 3;   // launch bounds: three waves per SIMD
       c->occ_tpr_blocks = static_cast<uint32_t>(nb);
-      c->occ_tpr_lds = Lt.total;
+      c->occ_tpr_lds = occ_key;
     }
     const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
     uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);

@@ -345,15 +345,18 @@ def test_lane_transpose_reduce(Smpc):
 
 
 @pytest.mark.parametrize("B,T,M", [(1000, 30, 200), (4096, 64, 200), (8192, 64, 2000), (2500, 56, 200),
-                                   (2500, 100, 200), (300, 61, 200), (65, 3, 200), (64, 1, 200)])
+                                   (2500, 100, 200), (300, 61, 200), (65, 3, 200), (64, 1, 200),
+                                   (4096, 128, 2000), (3000, 128, 200), (130, 128, 200)])
 def test_lane_per_rollout_pass_parity(Smpc, Oracle, B, T, M):
     """The lane-per-rollout pass (csrc/smpc_lane.hip: lane = rollout, sequential in time,
-    parked controls, in-register transpose-reduce) against the oracle.  Cruise ticks take it
-    for T <= 64; near-goal ticks (GoalAngle active) and T > 64 fall back to the wave pass."""
+    in-register transpose-reduce) against the oracle.  Cruise ticks take it for T <= 64 with the
+    controls parked in registers and for T = 128 in its re-read form; near-goal ticks
+    (GoalAngle active) and the other horizons above 64 fall back to the wave pass."""
     for near in (False, True):
         cfg, scn, noise = make_case(B, T, map_size=M, near_goal=near)
         cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
         g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+        assert og.pass_kind == (1 if (not near and (T <= 64 or T == 128)) else 0)
         assert og.non_colliding == oo.non_colliding
         assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1,
                       label=f"lane pass {B}x{T} near={near}")
@@ -614,3 +617,27 @@ def test_fused_time_major_fill_is_the_same_stream(Smpc, monkeypatch, B, T, off):
     plain.redraw_noise()
     for a, b in zip(fused.get_noise(), plain.get_noise()):
         assert np.array_equal(a, b)
+
+
+def test_lane_pass_reread_form_at_64_steps(Smpc, Oracle, monkeypatch):
+    """The re-read form of the lane pass (the one T = 128 takes) forced onto a 64-step horizon:
+    the same tick as the parked form, to the last bit of the costs (the rollout is the same
+    code; only where the weighted sum's operands come from differs: c = u + n formed again from
+    the noise, with the same single rounding) and within float reassociation on u."""
+    cfg, scn, noise = make_case(8192, 64)
+    cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+    parked = Smpc(cfg)
+    configure(parked, scn, noise=noise)
+    u_p, out_p = parked.optimize(scn.tick, scn.u0)
+    monkeypatch.setenv("SMPC_LANE_REREAD", "1")
+    rr = Smpc(cfg)
+    configure(rr, scn, noise=noise)
+    u_r, out_r = rr.optimize(scn.tick, scn.u0)
+    assert out_p.pass_kind == out_r.pass_kind == 1
+    assert np.array_equal(parked.get_costs(), rr.get_costs())
+    assert out_p.furthest_reached_path_point == out_r.furthest_reached_path_point
+    np.testing.assert_allclose(u_r, u_p, rtol=2e-6, atol=2e-7)
+    o = Oracle(cfg)
+    configure(o, scn, noise=noise)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert_parity(u_r, out_r, uo, oo, rr.get_costs(), o.get_costs(), label="re-read form, 8192x64")

@@ -67,7 +67,7 @@ def test_per_gpu_share_262144x64_lane_pass():
 
 def test_cfg3_full_size_262144x128():
     """BASELINE configs[2] at full size: 262 144 x 128 on the 2000 x 2000 map."""
-    _run(262144, 128, 2000, None, 8, "262144x128 2000x2000")
+    _run(262144, 128, 2000, True, 8, "262144x128 2000x2000")
 
 
 def test_headline_2097152x64():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: one-shot check of a kernel change — parity of the lane pass against the oracle
-on a small batch (costs, flips, Twist), then the scoring pass's duration (HIP events) and the
+on small batches (costs, flips, Twist), then the scoring pass's duration (HIP events) and the
 tick's wall time at the bench sizes.  Needs a GPU.   python tools/kbench.py [tag]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ from oracle.loader import Oracle, build
 
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 build()
-for (B, T, M) in ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000)):
+for (B, T, M) in ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000), (4096, 128, 2000), (8192, 128, 200)):
     cfg, scn, noise = make_case(B, T, map_size=M)
     cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
     g, o = Smpc(cfg), Oracle(cfg)
@@ -21,13 +21,13 @@ for (B, T, M) in ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000)):
         configure(obj, scn, noise=noise)
     ug, og = g.optimize(scn.tick, scn.u0)
     uo, oo = o.optimize(scn.tick, scn.u0)
-    assert og.pass_kind == 1
-    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"{tag} {B}x{T} map {M}")
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
+                  label=f"{tag} {B}x{T} map {M} pass_kind {og.pass_kind}")
     g.close()
 
 import torch
-for B in (262144, 2097152):
-    g, scn, cfg = make_ctx(B, 64, 200)
+for (B, T, M) in ((262144, 64, 200), (2097152, 64, 200), (262144, 128, 2000)):
+    g, scn, cfg = make_ctx(B, T, M)
     u = scn.u0
     for _ in range(5):
         un, out = g.optimize(scn.tick, u); u = shift(un)
@@ -42,8 +42,8 @@ for B in (262144, 2097152):
     for _ in range(40):
         un, out = g.optimize(scn.tick, u); u = shift(un)
         ps.append(out.score_pass_ms)
-    by = algorithmic_bytes(B, 64, 200, 200, 60)
+    by = algorithmic_bytes(B, T, M, M, 60)
     p = float(np.median(ps))
-    print(f"[kbench {tag}] {B}x64: pass {p*1e3:.1f} us ({by/p/1e6/8000:.3f} of 8 TB/s), tick {el*1e6:.1f} us "
-          f"({by/el/1e9/8000:.3f}), passes/tick {out.passes}")
+    print(f"[kbench {tag}] {B}x{T} map {M}: pass {p*1e3:.1f} us ({by/p/1e6/8000:.3f} of 8 TB/s), tick {el*1e6:.1f} us "
+          f"({by/el/1e9/8000:.3f}), passes/tick {out.passes}, pass_kind {out.pass_kind}")
     g.close()
