@@ -65,6 +65,60 @@ int sortham_optimizer_get_optimized_trajectory(sortham_optimizer* o, float* xyya
  * history = 4 x {vx, vy, wz}, oldest first.  No GPU involved. */
 void sortham_utils_savitsky_golay(float* u, uint32_t T, float* history, int shift_control_sequence);
 
+/* ---- PathHandler for plain types [ref src/path_handler.cpp:25-220, tools/path_handler.hpp:46-165]
+ * Poses are {x, y, yaw} triples of doubles.  What tf2 supplies in the reference comes in as
+ * arguments: the robot pose already in the plan's frame and the rigid transform
+ * {tx, ty, yaw} from the plan's frame to the costmap's (NULL = identity). */
+typedef struct sortham_path_handler sortham_path_handler;
+typedef struct sortham_path_handler_config {
+  uint32_t costmap_size_x, costmap_size_y;          /* Costmap2D::getSizeInCellsX / Y                  */
+  double costmap_resolution, costmap_origin_x, costmap_origin_y;
+  double max_robot_pose_search_dist;                /* < 0: getMaxCostmapDist() [ref :39,166-171]       */
+  double prune_distance;                            /* [ref :40] default 1.5                            */
+  int32_t enforce_path_inversion;                   /* [ref :42]                                        */
+  float inversion_xy_tolerance, inversion_yaw_tolerance; /* [ref :44-45]                                */
+} sortham_path_handler_config;
+void sortham_path_handler_config_default(sortham_path_handler_config* c);
+int sortham_path_handler_create(const sortham_path_handler_config* cfg, sortham_path_handler** out);
+void sortham_path_handler_destroy(sortham_path_handler* h);
+const char* sortham_path_handler_last_error(const sortham_path_handler* h);
+/* setPath [ref :173-180]: poses = n x {x, y, yaw} */
+int sortham_path_handler_set_path(sortham_path_handler* h, const double* poses, uint32_t n);
+/* getPath [ref :182] / the plan up to the first inversion: copies at most cap poses, returns the count */
+uint32_t sortham_path_handler_get_path(const sortham_path_handler* h, int up_to_inversion, double* poses, uint32_t cap);
+/* transformPath [ref :123-145]; SORTHAM_ERR_THROWN where the reference throws */
+int sortham_path_handler_transform_path(sortham_path_handler* h, const double* robot_pose_in_plan_frame,
+                                        const double* plan_to_costmap, double* poses_out, uint32_t cap,
+                                        uint32_t* n_out);
+/* getGlobalPlanConsideringBoundsInCostmapFrame [ref :48-103] without pruning; *closest = index of the
+ * plan pose closest to the robot */
+int sortham_path_handler_plan_in_bounds(sortham_path_handler* h, const double* robot_pose_in_plan_frame,
+                                        const double* plan_to_costmap, double* poses_out, uint32_t cap,
+                                        uint32_t* n_out, uint32_t* closest);
+int sortham_path_handler_prune(sortham_path_handler* h, int up_to_inversion, uint32_t end);   /* prunePlan [ref :184-187] */
+int sortham_path_handler_transformed_goal(sortham_path_handler* h, const double* plan_to_costmap, double* pose_out);
+int sortham_path_handler_within_inversion_tolerances(const sortham_path_handler* h, const double* robot_pose);
+double sortham_path_handler_max_costmap_dist(const sortham_path_handler* h);
+/* utils::findFirstPathInversion / removePosesAfterFirstInversion [ref tools/utils.hpp:612-658];
+ * the second edits poses in place and writes the new count to *n */
+uint32_t sortham_utils_find_first_path_inversion(const double* poses, uint32_t n);
+uint32_t sortham_utils_remove_poses_after_first_inversion(double* poses, uint32_t* n);
+
+/* ---- TrajectoryVisualizer's marker lists [ref src/trajectory_visualizer.cpp:59-128] ----
+ * A marker comes back as 10 doubles {id, x, y, z, scale x, y, z, g, b, a} (r is always 0). */
+typedef struct sortham_trajectory_visualizer sortham_trajectory_visualizer;
+int sortham_visualizer_create(const char* frame_id, int trajectory_step, int time_step,
+                              sortham_trajectory_visualizer** out);
+void sortham_visualizer_destroy(sortham_trajectory_visualizer* v);
+/* add(optimal trajectory): n rows of `stride` floats, x and y first [ref :59-83] */
+int sortham_visualizer_add_trajectory(sortham_trajectory_visualizer* v, const float* xy, uint32_t n, uint32_t stride);
+/* add(candidate trajectories): x, y [B][T] [ref :85-107] */
+int sortham_visualizer_add_candidates(sortham_trajectory_visualizer* v, const float* x, const float* y,
+                                      uint32_t B, uint32_t T);
+/* visualize() [ref :115-126]: what would be published; copies at most cap markers, returns the count, resets */
+uint32_t sortham_visualizer_visualize(sortham_trajectory_visualizer* v, double* markers, uint32_t cap);
+const char* sortham_visualizer_frame(const sortham_trajectory_visualizer* v);
+
 #ifdef __cplusplus
 }
 #endif
