@@ -102,6 +102,8 @@ struct SmpcDev {
   float con_acker_r;   // Ackermann min_turning_r (constraint_critic.cpp:54-59), < 0: other models
   const float* lut_cost;                         // [256] CostCritic repulsive term per 8-bit cost
   float cost_w254, cost_collision_cost;          // cost_weight / 254 (cost_critic.cpp:34)
+  float cost_critical;                           // critical_cost (cost_critic.cpp:144-147)
+  uint32_t cost_near_goal;                       // robot within near_goal_distance: no repulsion (:120-124,150)
   uint32_t cost_power;
   double goal_x, goal_y;
   float goal_weight;

@@ -238,6 +238,10 @@ __device__ __forceinline__ float seg_scan_add(float v, uint32_t seg_shift)
 //   MODE 1: rollout + endpoint argmin only (utils::findPathFurthestReachedPoint,
 //           tools/utils.hpp:292-319)
 //   MODE 2: score, general cost_power (pow in double per critic)
+//   MODE 3: MODE 0 plus the additive forms of CostCritic, GoalCritic, ConstraintCritic,
+//           TwirlingCritic and PathAngleCritic (every cost_power == 1): the deployed critic
+//           list (robot_bringup/config/nav2_params.yaml:222) in ONE wave reduction instead of
+//           one double-precision reduction and one pow per critic
 //   FULL:   T == 64*R, every lane owns R valid steps (no tail predicates)
 //
 // A wave rolls out one rollout at a time (lane = time step) and PARKS it: its noised
@@ -254,7 +258,8 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   // MODE 0 is the lean kernel: the rarely used features (trajectory write-out, path
   // orientations, the near-goal GoalAngle term) live only in MODE 2, so their pointers and
   // parameters do not occupy scalar registers in the hot loop
-  constexpr bool RARE = MODE != 0;
+  constexpr bool RARE = MODE != 0 && MODE != 3;
+  constexpr bool EXTRA = MODE == 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
@@ -675,6 +680,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
     float cost = (p.flags & SD_ACCUMULATE) ? p.costs_prev[b] : 0.f;
     float lin = 0.f;    // MODE 0: per-lane sum of every additive per-step term
     float uni = 0.f;    // MODE 0: wave-uniform terms
+    double lin_d = 0.0; // MODE 3: per-lane sum of the terms the reference forms in double
 
     // ---- ConstraintCritic (constraint_critic.cpp:41-75); MODE 2 only.  With the Ackermann
     //      model (con_acker_r >= 0) each step also pays min_turning_r - |vx|/|wz| (:54-69;
@@ -699,6 +705,24 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
         }
       }
       cost = add_cost_pow(cost, wave_sum_d(sa) * (double)p.con_weight, p.con_power);
+    }
+
+    if (EXTRA && (p.flags & SD_CONSTRAINT)) {
+      // the same per-step double arithmetic; with cost_power == 1 the critic's total is additive
+      const double kw = (double)p.dt * (double)p.con_weight;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (STEP_OK(r)) {
+          const double sgn = vx[r] > 0.0f ? 1.0 : -1.0;
+          const double vel_total = sgn * (double)sqrtf(vx[r] * vx[r] + vy[r] * vy[r]);
+          double e = fmax(vel_total - (double)p.con_max_vel, 0.0) + fmax((double)p.con_min_vel - vel_total, 0.0);
+          if (p.con_acker_r >= 0.f) {
+            const double q = (double)(p.con_acker_r - fabsf(vx[r]) / fabsf(wz[r]));
+            e += q > 0.0 ? q : 0.0;
+          }
+          lin_d += e * kw;
+        }
+      }
     }
 
     // ---- consider_footprint = true for either collision critic: MODE 2 only ----------
@@ -796,6 +820,9 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
             crit += e.crit;
             rep += e.rep;
             if (RARE && (p.flags & SD_COST)) crep += p.lut_cost[c];
+            // cost_critic.cpp:141-155 per 8-bit cost, as arithmetic (the table sits in global memory)
+            if (EXTRA && (p.flags & SD_COST) && c >= 1u)
+              crep += c >= 253u ? p.cost_critical : (p.cost_near_goal ? 0.f : (float)c);
           }
         }
       }
@@ -812,6 +839,11 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
         const float repulsive = collided ? p.cost_collision_cost : wave_sum(crep);
         const float v = p.cost_w254 * repulsive / (float)T;
         cost = add_cost_pow(cost, (double)v, p.cost_power);
+      }
+      if (EXTRA && (p.flags & SD_COST)) {
+        const float k = p.cost_w254 / (float)T;
+        if (collided) uni += k * p.cost_collision_cost;
+        else lin += k * crep;
       }
       if (p.flags & SD_OBSTACLES) {
         if (GENERIC) {
@@ -913,6 +945,44 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       cost = add_cost_pow(cost, wave_sum_d(sa) * (double)p.db_weight, p.db_power);
     }
 
+    if (EXTRA) {
+      if (p.flags & SD_GOAL) {
+        const double kw = (double)p.goal_weight / (double)T;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (STEP_OK(r)) {
+            const double ddx = (double)x[r] - p.goal_x, ddy = (double)y[r] - p.goal_y;
+            lin_d += sqrt(ddx * ddx + ddy * ddy) * kw;
+          }
+        }
+      }
+      if ((p.flags & SD_PATH_ANGLE) && p.pang_active[S]) {
+        const uint32_t idx = min(S + p.pang_offset, p.P - 1);
+        const float tgx = s_px[idx], tgy = s_py[idx];
+        const double kw = (double)p.pang_weight / (double)T;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (STEP_OK(r)) {
+            const float ybp = atan2f(tgy - y[r], tgx - x[r]);
+            const double d = fabs(normalize_angle((double)(ybp - yaw[r])));
+            if (p.pang_correct) {
+              const double ybp_c = d < M_PI_2 ? (double)ybp : normalize_angle((double)ybp + M_PI);
+              lin_d += fabs(normalize_angle(ybp_c - (double)yaw[r])) * kw;
+            } else {
+              lin_d += d * kw;
+            }
+          }
+        }
+      }
+      if (p.flags & SD_TWIRLING) {
+        const double kw = (double)p.tw_weight / (double)T;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (STEP_OK(r)) lin_d += (double)fabsf(wz[r]) * kw;
+        }
+      }
+    }
+
     // ---- updateControlSequence gamma terms (optimizer.cpp:365-380) -----------
     if (GENERIC) {
       float gx = 0.f, gz = 0.f, gy = 0.f;
@@ -932,7 +1002,8 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
         lin = fmaf(guz[r], cwz[r] - uwz[r], lin);
         lin = fmaf(guy[r], cvy[r] - uvy[r], lin);
       }
-      cost += uni + wave_sum(lin);
+      if (EXTRA) cost += uni + (float)wave_sum_d(lin_d + (double)lin);
+      else cost += uni + wave_sum(lin);
     }
 
     // ---- park the rollout -----------------------------------------------------
@@ -1460,7 +1531,8 @@ static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint3
   return hipGetLastError();
 }
 
-// mode: 0 score (all cost_power == 1), 1 furthest only, 2 score (general cost_power)
+// mode: 0 score (all cost_power == 1), 1 furthest only, 2 score (general cost_power),
+// 3 score (all cost_power == 1, with the additive forms of Cost, Goal, Constraint, Twirling, PathAngle)
 hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
                             uint32_t grid, uint32_t block, hipStream_t st)
 {
@@ -1470,6 +1542,8 @@ hipError_t smpc_launch_pass(int R, int mode, const SmpcDev& p, const SmpcLds& L,
                         : launch_pass_r<0, false>(R, p, L, grid, block, st);
     case 1: return full ? launch_pass_r<1, true>(R, p, L, grid, block, st)
                         : launch_pass_r<1, false>(R, p, L, grid, block, st);
+    case 3: return full ? launch_pass_r<3, true>(R, p, L, grid, block, st)
+                        : launch_pass_r<3, false>(R, p, L, grid, block, st);
     default: return full ? launch_pass_r<2, true>(R, p, L, grid, block, st)
                          : launch_pass_r<2, false>(R, p, L, grid, block, st);
   }
@@ -1481,6 +1555,7 @@ static void for_each_pass_kernel(F&& f)
 #define EACH(RR, MM) f(reinterpret_cast<const void*>(&smpc_pass<RR, MM, true>), RR, MM, true); \
                      f(reinterpret_cast<const void*>(&smpc_pass<RR, MM, false>), RR, MM, false);
   EACH(1, 0) EACH(2, 0) EACH(4, 0) EACH(1, 1) EACH(2, 1) EACH(4, 1) EACH(1, 2) EACH(2, 2) EACH(4, 2)
+  EACH(1, 3) EACH(2, 3) EACH(4, 3)
 #undef EACH
 }
 

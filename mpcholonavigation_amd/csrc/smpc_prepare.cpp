@@ -323,7 +323,19 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   // persistent grid: as many blocks as stay resident, never more than the work
   const uint32_t waves_per_block = (pass_block(c->R) / 64);
   int mode_now = c->score_mode_for(cr);
-  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | SD_EXTRA_CRITICS)) mode_now = 2;   // lean kernels lack these
+  // the lean kernels: MODE 0 scores the north star's five, MODE 3 also the additive forms of Cost,
+  // Goal, Constraint, Twirling and PathAngle (the deployed list); everything else (a cost_power
+  // other than 1, trajectory write-out, path orientations, an active GoalAngle term, a footprint,
+  // VelocityDeadband) takes the general pass
+  const uint32_t lean_extra = SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE;
+  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | (SD_EXTRA_CRITICS & ~lean_extra))) {
+    mode_now = 2;
+  } else if (gates & lean_extra) {
+    const bool unit_powers = (!cr.constraint.enabled || cr.constraint.cost_power == 1) &&
+      (!cr.cost.enabled || cr.cost.cost_power == 1) && (!cr.goal.enabled || cr.goal.cost_power == 1) &&
+      (!cr.twirling.enabled || cr.twirling.cost_power == 1) && (!cr.path_angle.enabled || cr.path_angle.cost_power == 1);
+    mode_now = (mode_now == 0 && unit_powers) ? 3 : 2;
+  }
   if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
     int nb = 0;
     if (smpc_pass_occupancy(c->R, mode_now, T == 64u * static_cast<uint32_t>(c->R), pass_block(c->R), c->lds.total, &nb) != hipSuccess || nb < 1) nb = 1;
@@ -537,9 +549,11 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     memset(pang_active, 0, std::max(P, 1u));
   }
   float* lut_cost = reinterpret_cast<float*>(h + tl.lut_cost);
+  bool near_goal_cost = false;
   if (gates & SD_COST) {
     // cost_critic.cpp:120-124,141-155 per 8-bit cost (collisions are marked in the shared LUT)
     const bool near_goal_c = within_tol(cr.cost.near_goal_distance, rx, ry, gx, gy);
+    near_goal_cost = near_goal_c;
     for (int v = 0; v < 256; ++v) {
       float t = 0.0f;
       if (v >= 1) {
@@ -636,6 +650,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.lut_cost = reinterpret_cast<const float*>(c->d_tick + tl.lut_cost);
   d.cost_w254 = cr.cost.cost_weight / 254.0f;   // cost_critic.cpp:34
   d.cost_collision_cost = cr.cost.collision_cost; d.cost_power = cr.cost.cost_power;
+  d.cost_critical = cr.cost.critical_cost;
+  d.cost_near_goal = near_goal_cost ? 1u : 0u;
   d.goal_x = in->goal_x; d.goal_y = in->goal_y;
   d.goal_weight = cr.goal.cost_weight; d.goal_power = cr.goal.cost_power;
   d.tw_weight = cr.twirling.cost_weight; d.tw_power = cr.twirling.cost_power;
