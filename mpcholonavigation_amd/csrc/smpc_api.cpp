@@ -87,7 +87,10 @@ void fill_score_args(smpc_ctx* c, uint32_t flags, const float* u_dev, const floa
 {
   d = c->dev;
   d.flags = flags;
-  if (u_dev) d.u = u_dev;
+  if (u_dev) {        // a later iteration: the control sequence the previous one left on the device
+    d.u = u_dev;
+    d.u_inline = 0;
+  }
   d.d_furthest = d_furthest;
   d.furthest_hint = furthest_hint;
   d.costs = c->d_costs[c->costs_cur];

@@ -132,7 +132,55 @@ struct SmpcDev {
   uint32_t* furthest_out;  // atomicMax target of the furthest-only pass (float bits)
   // developer aid (SMPC_LANE_TIMELINE=1): [gridDim.x][8] shader-clock stamps of the lane pass
   unsigned long long* timeline;
+  // The tick block INSIDE the kernel arguments (small ticks: T <= 64, P <= 64).  The per-tick
+  // upload is ~2 KB that the whole grid needs before its first instruction; as a separate
+  // host-to-device copy it costs a blit kernel (3.4 us) and the dependency gap behind it
+  // (4 us) on every tick.  Kernel arguments travel with the dispatch packet instead: the
+  // kernels read u, the path and its tables straight from their own kernarg segment
+  // (smpc_tick_ptrs).  tick_inline = 0: the pointers above (device memory) are used.
+  uint32_t tick_inline;        // the path block is in tick_bytes
+  uint32_t u_inline;           // ... and so is u (0: p.u, e.g. the previous iteration's result on the device)
+  uint16_t io_u, io_px, io_py, io_pyaw, io_D, io_pf_idx, io_pvalid, io_pa_active, io_pang_active, io_pad[3];
+  uint8_t tick_bytes[2304] __attribute__((aligned(16)));
 };
+#define SMPC_INLINE_TICK_CAP 2304u
+
+#if defined(__HIPCC__)
+// where a kernel whose FIRST parameter is the SmpcDev finds the tick block (see tick_inline)
+struct SmpcTickPtrs {
+  const float* u;
+  const float* px;
+  const float* py;
+  const float* pyaw;
+  const float* D;
+  const uint32_t* pf_idx;
+  const uint8_t* pvalid;
+  const uint8_t* pa_active;
+  const uint8_t* pang_active;
+};
+__device__ __forceinline__ SmpcTickPtrs smpc_tick_ptrs(const SmpcDev& p, bool kernarg_is_dev)
+{
+  SmpcTickPtrs t{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active};
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (kernarg_is_dev && p.tick_inline) {
+    const uint8_t* k = reinterpret_cast<const uint8_t*>(__builtin_amdgcn_kernarg_segment_ptr()) +
+                       __builtin_offsetof(SmpcDev, tick_bytes);
+    if (p.u_inline) t.u = reinterpret_cast<const float*>(k + p.io_u);
+    t.px = reinterpret_cast<const float*>(k + p.io_px);
+    t.py = reinterpret_cast<const float*>(k + p.io_py);
+    t.pyaw = reinterpret_cast<const float*>(k + p.io_pyaw);
+    t.D = reinterpret_cast<const float*>(k + p.io_D);
+    t.pf_idx = reinterpret_cast<const uint32_t*>(k + p.io_pf_idx);
+    t.pvalid = k + p.io_pvalid;
+    t.pa_active = k + p.io_pa_active;
+    t.pang_active = k + p.io_pang_active;
+  }
+#else
+  (void)kernarg_is_dev;
+#endif
+  return t;
+}
+#endif
 
 // The furthest reached path point travels as ONE float F = S + f: S the index (max over the
 // rollouts of the path point nearest to the rollout's endpoint, tools/utils.hpp:292-319) and

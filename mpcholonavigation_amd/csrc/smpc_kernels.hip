@@ -269,6 +269,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   float* s_D = reinterpret_cast<float*>(smem + L.off_D);
   uint8_t* s_valid = smem + L.off_valid;
 
+  const SmpcTickPtrs tk = smpc_tick_ptrs(p, true);
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   // wave-uniform by construction: tell the compiler, so that the rollout index, the row
@@ -305,13 +306,13 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       const_cast<SmpcLut*>(s_lut)[i] = p.lut[i];
   }
   for (uint32_t i = tid; i < p.P; i += blockDim.x) {
-    s_px[i] = p.px[i];
-    s_py[i] = p.py[i];
+    s_px[i] = tk.px[i];
+    s_py[i] = tk.py[i];
     if (!FURTHEST_ONLY) {
-      s_pyaw[i] = p.pyaw[i];
+      s_pyaw[i] = tk.pyaw[i];
       if (i + 1 < p.P) {
-        s_D[i] = p.D[i];
-        s_valid[i] = p.pvalid[i];
+        s_D[i] = tk.D[i];
+        s_valid[i] = tk.pvalid[i];
       }
     }
   }
@@ -325,9 +326,9 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool a = STEP_OK(r);
-    uvx[r] = a ? p.u[t0 + r] : 0.f;
-    uvy[r] = a ? p.u[T + t0 + r] : 0.f;
-    uwz[r] = a ? p.u[2 * T + t0 + r] : 0.f;
+    uvx[r] = a ? tk.u[t0 + r] : 0.f;
+    uvy[r] = a ? tk.u[T + t0 + r] : 0.f;
+    uwz[r] = a ? tk.u[2 * T + t0 + r] : 0.f;
   }
   const float dt = in_vgpr(p.dt);
   const float yaw0_v = in_vgpr(p.yaw0);
@@ -359,9 +360,9 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       S = p.d_furthest ? smpc_furthest_index(*p.d_furthest) : p.furthest_hint;
       if (S >= p.P) S = p.P ? p.P - 1 : 0;
     }
-    pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && p.pa_active[S] && S > 0;
+    pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && tk.pa_active[S] && S > 0;
     if ((p.flags & SD_PATH_FOLLOW) && p.P > 0) {
-      const uint32_t idx = p.pf_idx[S];
+      const uint32_t idx = tk.pf_idx[S];
       pf_x = s_px[idx];
       pf_y = s_py[idx];
     }
@@ -904,7 +905,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       }
       cost = add_cost_pow(cost, wave_sum_d(sa) / (double)T * (double)p.goal_weight, p.goal_power);
     }
-    if (RARE && (p.flags & SD_PATH_ANGLE) && p.pang_active[S]) {
+    if (RARE && (p.flags & SD_PATH_ANGLE) && tk.pang_active[S]) {
       // path_angle_critic.cpp:72-100: float atan2, then the double angle arithmetic of
       // utils::shortest_angular_distance / normalize_angles (tools/utils.hpp:258-284)
       const uint32_t idx = min(S + p.pang_offset, p.P - 1);
@@ -956,7 +957,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
           }
         }
       }
-      if ((p.flags & SD_PATH_ANGLE) && p.pang_active[S]) {
+      if ((p.flags & SD_PATH_ANGLE) && tk.pang_active[S]) {
         const uint32_t idx = min(S + p.pang_offset, p.P - 1);
         const float tgx = s_px[idx], tgy = s_py[idx];
         const double kw = (double)p.pang_weight / (double)T;

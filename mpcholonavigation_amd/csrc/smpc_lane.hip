@@ -254,6 +254,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
 {
   static_assert(RR || NCH == 1, "parked controls: one chunk of 64 steps");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
+  const SmpcTickPtrs tk = smpc_tick_ptrs(p, !MANY);   // (MANY: the parameter block is not the kernarg segment)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
@@ -301,9 +302,9 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     }
     const SmpcLut lut_e = (OBST && tid < 256) ? p.lut[tid] : SmpcLut{0.f, 0.f};
     const bool pt_on = (uint32_t)tid < p.P, seg_on = (uint32_t)tid + 1 < p.P;
-    const float g_px = pt_on ? p.px[tid] : 0.f, g_py = pt_on ? p.py[tid] : 0.f;
-    const float g_D = seg_on ? p.D[tid] : 0.f;
-    const bool g_valid = seg_on && p.pvalid[tid] != 0;
+    const float g_px = pt_on ? tk.px[tid] : 0.f, g_py = pt_on ? tk.py[tid] : 0.f;
+    const float g_D = seg_on ? tk.D[tid] : 0.f;
+    const bool g_valid = seg_on && tk.pvalid[tid] != 0;
 
     if (OBST) {
 #pragma unroll
@@ -334,12 +335,12 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       s_pts4[tid] = f32x4{g_px, g_py, g_valid ? 1.0f : 0.f, 0.f};
     }
     for (uint32_t i = tid + BLK; i < p.P; i += BLK) {   // paths beyond one point per thread
-      const float qx = p.px[i], qy = p.py[i];
+      const float qx = tk.px[i], qy = tk.py[i];
       const bool seg = i + 1 < p.P;
       s_px[i] = qx;
       s_py[i] = qy;
-      if (seg) s_D[i] = p.D[i];
-      s_pts4[i] = f32x4{qx, qy, (seg && p.pvalid[i]) ? 1.0f : 0.f, 0.f};
+      if (seg) s_D[i] = tk.D[i];
+      s_pts4[i] = f32x4{qx, qy, (seg && tk.pvalid[i]) ? 1.0f : 0.f, 0.f};
     }
   }
   __syncthreads();
@@ -348,7 +349,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // ---- constants (wave-uniform: scalar registers) -------------------------------
   // u and the path are inputs of the launch: read them through the constant address space,
   // so that uniform loads stay scalar loads although the kernel also stores to global memory
-  const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
+  const cfloat_p cu = (cfloat_p)(uintptr_t)tk.u;
   const uint32_t T = FULL ? 64u * NCH : p.T, B = p.B;
   // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
   // three tensors, the lane's own offset (b * 4) is the vector offset
@@ -371,16 +372,16 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     s_D[-1] = -3.0e38f;
     s_D[S] = 3.0e38f;
   }
-  const bool pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && p.pa_active[S] && S > 0;
+  const bool pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && tk.pa_active[S] && S > 0;
   float pf_x = 0.f, pf_y = 0.f;
   if ((p.flags & SD_PATH_FOLLOW) && p.P > 0) {
-    const uint32_t idx = p.pf_idx[S];
-    pf_x = p.px[idx];
-    pf_y = p.py[idx];
+    const uint32_t idx = tk.pf_idx[S];
+    pf_x = tk.px[idx];
+    pf_y = tk.py[idx];
   }
   const uint32_t bs_iters = S > 1 ? 32u - (uint32_t)__builtin_clz(S - 1) : 0u;
   float pa_inv_spacing = 0.f;
-  if (pa_on && S > 1 && p.D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / p.D[S - 1];
+  if (pa_on && S > 1 && tk.D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / tk.D[S - 1];
   const bool want_local_furthest = (p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST);
   const uint32_t nquad = (T + 3u) >> 2;
 
