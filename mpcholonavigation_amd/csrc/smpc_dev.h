@@ -138,12 +138,16 @@ struct SmpcDev {
   // (4 us) on every tick.  Kernel arguments travel with the dispatch packet instead: the
   // kernels read u, the path and its tables straight from their own kernarg segment
   // (smpc_tick_ptrs).  tick_inline = 0: the pointers above (device memory) are used.
-  uint32_t tick_inline;        // the path block is in tick_bytes
-  uint32_t u_inline;           // ... and so is u (0: p.u, e.g. the previous iteration's result on the device)
-  uint16_t io_u, io_px, io_py, io_pyaw, io_D, io_pf_idx, io_pvalid, io_pa_active, io_pang_active, io_pad[3];
-  uint8_t tick_bytes[2304] __attribute__((aligned(16)));
+  uint32_t tick_inline;        // the path and its tables are in tick_bytes
+  uint32_t u_inline;           // u is in u_arg (0: p.u, e.g. the previous iteration's result on the device)
+  uint16_t io_px, io_py, io_pyaw, io_D, io_pf_idx, io_pvalid, io_pa_active, io_pang_active;
+  uint8_t tick_bytes[1536] __attribute__((aligned(16)));
+  // The control sequence u[3][T] of a tick with T <= 64 (u_inline).  Only the wave-per-rollout
+  // pass, which reads u once, takes its tick block from the kernel arguments; the
+  // lane-per-rollout pass re-reads u for every group and keeps it in device memory.
+  float u_arg[3 * 64] __attribute__((aligned(16)));
 };
-#define SMPC_INLINE_TICK_CAP 2304u
+#define SMPC_INLINE_TICK_CAP 1536u
 
 #if defined(__HIPCC__)
 // where a kernel whose FIRST parameter is the SmpcDev finds the tick block (see tick_inline)
@@ -165,7 +169,8 @@ __device__ __forceinline__ SmpcTickPtrs smpc_tick_ptrs(const SmpcDev& p, bool ke
   if (kernarg_is_dev && p.tick_inline) {
     const uint8_t* k = reinterpret_cast<const uint8_t*>(__builtin_amdgcn_kernarg_segment_ptr()) +
                        __builtin_offsetof(SmpcDev, tick_bytes);
-    if (p.u_inline) t.u = reinterpret_cast<const float*>(k + p.io_u);
+    if (p.u_inline) t.u = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(__builtin_amdgcn_kernarg_segment_ptr()) +
+                                                         __builtin_offsetof(SmpcDev, u_arg));
     t.px = reinterpret_cast<const float*>(k + p.io_px);
     t.py = reinterpret_cast<const float*>(k + p.io_py);
     t.pyaw = reinterpret_cast<const float*>(k + p.io_pyaw);

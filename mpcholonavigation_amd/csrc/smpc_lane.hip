@@ -254,7 +254,10 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
 {
   static_assert(RR || NCH == 1, "parked controls: one chunk of 64 steps");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
-  const SmpcTickPtrs tk = smpc_tick_ptrs(p, !MANY);   // (MANY: the parameter block is not the kernarg segment)
+  // (this pass reads its tick block from device memory only: it fetches u with scalar loads quad
+  // by quad, group after group, and reads of the kernarg segment are not cached the way plain
+  // device memory is — u inside the kernel arguments cost the 2 097 152-rollout pass 7 %)
+  const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);
@@ -349,7 +352,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // ---- constants (wave-uniform: scalar registers) -------------------------------
   // u and the path are inputs of the launch: read them through the constant address space,
   // so that uniform loads stay scalar loads although the kernel also stores to global memory
-  const cfloat_p cu = (cfloat_p)(uintptr_t)tk.u;
+  const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
   const uint32_t T = FULL ? 64u * NCH : p.T, B = p.B;
   // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
   // three tensors, the lane's own offset (b * 4) is the vector offset

@@ -593,12 +593,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev0, c->stream));
   // small ticks travel inside the kernel arguments (SmpcDev::tick_bytes) instead of a copy of
   // their own; the CostCritic table (general pass only) is not part of that
-  // (Reads of the kernarg segment are not served from L2: the lane-per-rollout pass, which
-  // fetches u with scalar loads quad by quad, group after group, pays for that once a wave owns
-  // more than two groups — measured +8 % on the 2 097 152-rollout pass — while the copy it saves
-  // is ~3 us: inline up to 262 144 rollouts per context.  The wave-per-rollout pass reads u once.)
-  const bool inline_tick = !c->defer_upload && tl.lut_cost <= SMPC_INLINE_TICK_CAP &&
-    !(c->use_tpr && B > 2u * kMaxGrid * 64u) && !getenv("SMPC_NO_INLINE_TICK");
+  // (contexts of the wave-per-rollout pass only: see smpc_lane.hip for why not the other)
+  const bool inline_tick = !c->defer_upload && !c->use_tpr && T <= 64 && tl.lut_cost - tl.px <= SMPC_INLINE_TICK_CAP &&
+    !getenv("SMPC_NO_INLINE_TICK");
   if (!c->defer_upload) {
     if (!inline_tick)
       HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
@@ -710,14 +707,16 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.neg_inv_temp = -1 / c->cfg.temperature;
   d.k2 = d.neg_inv_temp * 1.4426950408889634f;
   d.timeline = c->d_timeline;
+  if (inline_tick) memcpy(d.u_arg, h + tl.u, 3 * T * sizeof(float));
   if (inline_tick) {
     d.tick_inline = 1;
     d.u_inline = 1;
-    d.io_u = static_cast<uint16_t>(tl.u); d.io_px = static_cast<uint16_t>(tl.px); d.io_py = static_cast<uint16_t>(tl.py);
-    d.io_pyaw = static_cast<uint16_t>(tl.pyaw); d.io_D = static_cast<uint16_t>(tl.D);
-    d.io_pf_idx = static_cast<uint16_t>(tl.pf_idx); d.io_pvalid = static_cast<uint16_t>(tl.pvalid);
-    d.io_pa_active = static_cast<uint16_t>(tl.pa_active); d.io_pang_active = static_cast<uint16_t>(tl.pang_active);
-    memcpy(d.tick_bytes, h, tl.lut_cost);
+    const size_t o = tl.px;   // the path block: everything between u and the CostCritic table
+    d.io_px = static_cast<uint16_t>(tl.px - o); d.io_py = static_cast<uint16_t>(tl.py - o);
+    d.io_pyaw = static_cast<uint16_t>(tl.pyaw - o); d.io_D = static_cast<uint16_t>(tl.D - o);
+    d.io_pf_idx = static_cast<uint16_t>(tl.pf_idx - o); d.io_pvalid = static_cast<uint16_t>(tl.pvalid - o);
+    d.io_pa_active = static_cast<uint16_t>(tl.pa_active - o); d.io_pang_active = static_cast<uint16_t>(tl.pang_active - o);
+    memcpy(d.tick_bytes, h + o, tl.lut_cost - o);
   }
   d.partials = c->d_partials;
   d.furthest_out = reinterpret_cast<uint32_t*>(c->d_furthest);
