@@ -472,6 +472,9 @@ int smpc_reset(smpc_ctx* c)
   HIPCK(c, hipMemsetAsync(c->d_costs[1], 0, c->cfg.batch_size * sizeof(float), c->stream));
   c->tick_ready = false;
   c->hint_valid = false;
+  c->hint_Fp_valid = false;
+  c->hint_is_this_ticks = false;
+  c->hint_drift = 0.f;
   if (c->rng_mode) {
     c->epoch++;
     return draw_noise(c);

@@ -231,6 +231,10 @@ struct smpc_ctx {
   // what the prediction starts from: the last known F = index + fraction (smpc_dev.h) and the
   // tick inputs it was measured on
   float hint_F = 0.f;
+  float hint_Fp = 0.f;       // the last prediction, unrounded; valid when hint_Fp_valid
+  bool hint_Fp_valid = false;
+  bool hint_is_this_ticks = false;   // set by the group's re-run of a missed member (predict_hint)
+  float hint_drift = 0.f;    // last tick's (true - predicted): how fast the endpoints drift relative to the robot
   bool anchor_valid = false;
   double anchor_x = 0, anchor_y = 0;
   std::vector<float> anchor_px, anchor_py;

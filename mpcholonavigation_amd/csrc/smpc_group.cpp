@@ -183,11 +183,14 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
       if (miss) {
         c->spec_misses++;
         remember_furthest(c, &ins[i], F_true);   // smpc_optimize speculates with the true value now: one pass
+        c->hint_is_this_ticks = true;
       }
       rc = single(i);
       if (rc != SMPC_OK) return rc;
+      if (outs) outs[i].passes++;    // the batched scoring this member took part in counts
       continue;
     }
+    if (need_f) remember_furthest(c, &ins[i], F_true);   // as smpc_optimize does: the predictor's state advances every tick
     store_control_sequence(c, u_inout[i]);
     if (outs) {
       smpc_tick_out* o = &outs[i];

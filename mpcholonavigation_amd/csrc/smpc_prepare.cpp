@@ -112,6 +112,20 @@ static void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut, bool cons
 
 void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F)
 {
+  // what the prediction for THIS tick missed is how far the rollouts' endpoints moved relative
+  // to the robot since the last tick (the control sequence is still changing: an accelerating
+  // robot reaches further every tick); to first order it does so again
+  static const bool trace = getenv("SMPC_TRACE_FURTHEST") != nullptr;
+  if (trace)
+    fprintf(stderr, "[smpc furthest] true %.3f predicted %.3f (geometry %.3f, valid %d, drift %.3f)\n", F,
+            c->hint_Fp + c->hint_drift, c->hint_Fp, (int)c->hint_Fp_valid, c->hint_drift);
+  if (c->hint_Fp_valid) {
+    const float d = F - c->hint_Fp;
+    c->hint_drift = std::fabs(d) < 2.f ? d : 0.f;
+  } else {
+    c->hint_drift = 0.f;
+  }
+  c->hint_Fp_valid = false;
   c->hint_F = F;
   c->hint = smpc_furthest_index(F);
   c->hint_valid = true;
@@ -136,6 +150,15 @@ void predict_hint(smpc_ctx* c, const smpc_tick_in* in)
   if (!c->hint_valid || !c->anchor_valid) return;
   const uint32_t P0 = static_cast<uint32_t>(c->anchor_px.size()), P = in->path_len;
   c->hint = smpc_furthest_index(c->hint_F);
+  if (c->hint_is_this_ticks) {
+    // smpc_group_optimize re-runs a member whose prediction missed: hint_F is this very tick's
+    // true value.  Score with it, and leave the drift as remember_furthest measured it.
+    c->hint_is_this_ticks = false;
+    c->hint_Fp = c->hint_F - c->hint_drift;
+    c->hint_Fp_valid = true;
+    return;
+  }
+  c->hint_Fp_valid = false;
   if (P0 < 2 || P < 1) return;
   const float* ox = c->anchor_px.data();
   const float* oy = c->anchor_py.data();
@@ -161,7 +184,10 @@ void predict_hint(smpc_ctx* c, const smpc_tick_in* in)
   if (!(seg2 > 0.f)) return;
   const float disp = static_cast<float>((in->pose_x - c->anchor_x) * sx + (in->pose_y - c->anchor_y) * sy) / seg2;
   if (!(std::fabs(disp) < 4.f)) return;     // a jump, not a controller period's motion
-  const float Fp = c->hint_F + disp - static_cast<float>(k);
+  const float Fp0 = c->hint_F + disp - static_cast<float>(k);   // carried by the geometry alone
+  const float Fp = Fp0 + c->hint_drift;                          // ... and by last tick's drift
+  c->hint_Fp = Fp0;
+  c->hint_Fp_valid = true;
   long h = std::lround(Fp);
   if (h < 0) h = 0;
   if (h > static_cast<long>(P) - 1) h = static_cast<long>(P) - 1;

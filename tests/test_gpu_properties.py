@@ -295,9 +295,13 @@ def test_grouped_contexts_tick_in_one_launch():
             us_a[i] = np.concatenate([ua[:, 1:], ua[:, -1:]], axis=1)
             us_g[i] = np.concatenate([ug[:, 1:], ug[:, -1:]], axis=1)
         kinds.append([o.passes for _, o in res_g])
-    # after the first tick (no furthest-point guess yet) every member rides the batched launch
+    print("[group] passes per member, per tick:", kinds)
+    # after the first tick (no furthest-point guess yet) the members ride the batched launch: a
+    # member scores twice only on the ticks its furthest-point prediction misses
     if not os.environ.get("SMPC_PASS"):
-        assert all(p == 1 for p in kinds[-1])
+        later = [p for row in kinds[1:] for p in row]
+        assert sum(p == 1 for p in later) >= len(later) - n - 2, kinds   # (tick 1 has no drift estimate yet)
+        assert all(p == 1 for p in kinds[-1]), kinds
     grp.close()
     for g in alone + grouped:
         g.close()
