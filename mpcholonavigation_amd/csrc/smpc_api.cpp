@@ -121,9 +121,25 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
   if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
   uint32_t nblk = c->grid;
+  const bool lane = c->lane_now && !(flags & SD_STORE_TRAJ);
+  if (lane) nblk = c->grid_tpr;
+  // The block that finishes last reduces the partials inside the scoring launch (smpc_tail.h);
+  // larger grids, and launches whose LDS was not sized for it, take the separate reduction.
+  if (c->poll_words > kPollWords) return fail(c, SMPC_ERR_UNSUPPORTED, "time_steps beyond the completion words");
+  const bool tail = c->fused_reduce && nblk <= SMPC_TAIL_MAX_GRID &&
+    (lane ? c->lds_tpr.total : c->lds.total) >= smpc_tail_lds_bytes(d.T);
+  // completion words: one per block of smpc_reduce_partials, or per reducing block of the tail
+  c->poll_words = (fin.enabled && fin.done_counter) ? (4u + 3u * d.T + 31u) / 32u : 0u;
+  if (tail) {
+    // (every reducing block publishes its own completion word: smpc_tail.h)
+    if (fin.enabled && fin.done_counter) c->poll_words = std::min((4u + 3u * d.T + 63u) / 64u, nblk);
+    d.tail = 1;
+    d.tail_counter = reinterpret_cast<uint32_t*>(c->d_furthest) + 4;
+    d.tuple = d_tuple;
+    d.fin = fin;
+  }
   // the lane-per-rollout pass scores with the full lean critic stack only
-  if (c->lane_now && !(flags & SD_STORE_TRAJ)) {
-    nblk = c->grid_tpr;
+  if (lane) {
     HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->lane_rr, c->stream));
     c->last_pass_kind = 1;
   } else {
@@ -136,7 +152,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
     HIPCK(c, hipEventRecord(c->evp[c->evp_used + 1], c->stream));
     c->evp_used += 2;
   }
-  HIPCK(c, smpc_launch_reduce(c->d_partials, nblk, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
+  if (!tail) HIPCK(c, smpc_launch_reduce(c->d_partials, nblk, d.T, d.neg_inv_temp, d_tuple, fin, c->stream));
   if (finish && c->acker_r >= 0.f)
     HIPCK(c, smpc_launch_ackermann(c->d_out, c->h_out_dev, d.T, c->acker_r, c->acker_seq, c->stream));
   c->passes++;
@@ -151,6 +167,7 @@ int launch_combine(smpc_ctx* c, const float* d_tuples, uint32_t n, const float* 
     seq = ++c->seq;
     if (seq == 0) seq = ++c->seq;
     c->poll_seq = seq;
+    c->poll_words = 0;   // (one word, written by the combining block)
   }
   const bool acker = c->acker_r >= 0.f;
   HIPCK(c, smpc_launch_combine(d_tuples, n, T, c->dev.neg_inv_temp, c->c_vx_max, c->c_vx_min,
@@ -183,9 +200,20 @@ int fetch_out(smpc_ctx* c)
       reinterpret_cast<const volatile uint32_t*>(c->h_out + 3 * c->cfg.time_steps + 7);
     const uint32_t want = c->poll_seq;
     c->poll_seq = 0;
+    const uint32_t nwords = c->poll_words;   // > 0: one word per reducing block, from flag[1] on
+    c->poll_words = 0;
+    auto arrived = [&]() {
+      if (nwords == 0) return *flag == want;
+      for (uint32_t r = 0; r < nwords; ++r)
+        if (flag[1 + r] != want) return false;
+      return true;
+    };
     for (uint32_t spin = 0; spin < 4000000u; ++spin) {
-      if (*flag == want) {
+      if (arrived()) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        // smpc_grid_tail's mark: a reducing block gave up waiting for the grid's other blocks
+        if (c->h_out[3 * c->cfg.time_steps + 6] == 2.0f)
+          return fail(c, SMPC_ERR_DEVICE, "the scoring launch's reduction did not see every block's partial");
         return SMPC_OK;
       }
       __builtin_ia32_pause();
@@ -388,8 +416,9 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   c->stream = c->own_stream;
   c->poll_enabled = getenv("SMPC_NO_POLL") == nullptr;
   if (getenv("SMPC_LANE_TIMELINE")) {
-    CK(hipMalloc(&c->d_timeline, (8192 + kMaxGrid * 8) * sizeof(unsigned long long)));
-    CK(hipMemset(c->d_timeline, 0, (8192 + kMaxGrid * 8) * sizeof(unsigned long long)));
+    static_assert(SMPC_TAIL_STAMPS_AT == 8192 + kMaxGrid * 8, "the tail's stamps sit behind the lane pass's");
+    CK(hipMalloc(&c->d_timeline, (8192 + kMaxGrid * 8 + 8 * 16) * sizeof(unsigned long long)));
+    CK(hipMemset(c->d_timeline, 0, (8192 + kMaxGrid * 8 + 8 * 16) * sizeof(unsigned long long)));
   }
   CK(hipEventCreate(&c->ev0));
   CK(hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming));
@@ -446,10 +475,13 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipMalloc(&c->d_partials, kMaxGrid * TL * sizeof(float)));
   CK(hipMalloc(&c->d_tuple, TL * sizeof(float)));
   CK(hipMalloc(&c->d_out, (3 * T + 8) * sizeof(float)));
-  CK(hipHostMalloc(&c->h_out, (3 * T + 8) * sizeof(float), hipHostMallocMapped));
+  // [3T + 8 ...]: completion words, one per publishing block (at most 13: T = 128)
+  CK(hipHostMalloc(&c->h_out, (3 * T + 8 + kPollWords) * sizeof(float), hipHostMallocMapped));
+  memset(c->h_out, 0, (3 * T + 8 + kPollWords) * sizeof(float));
   CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_out_dev), c->h_out, 0));
-  CK(hipMalloc(&c->d_furthest, 16));
-  CK(hipMemset(c->d_furthest, 0, 16));
+  c->fused_reduce = getenv("SMPC_FUSED_REDUCE") != nullptr;   // (read per context: tests compare the two)
+  CK(hipMalloc(&c->d_furthest, 32));
+  CK(hipMemset(c->d_furthest, 0, 32));
   CK(smpc_set_pass_lds_limit(static_cast<int>(kLdsPerCu)));
   // the memsets above went to the default stream; the ctx works on its own non-blocking one
   CK(hipDeviceSynchronize());
@@ -856,6 +888,16 @@ int smpc_set_stream(smpc_ctx* c, void* hip_stream)
   const int rc = wait_map_upload(c);   // it went out on the stream being left
   if (rc != SMPC_OK) return rc;
   c->stream = hip_stream == SMPC_STREAM_OWN ? c->own_stream : static_cast<hipStream_t>(hip_stream);
+  return SMPC_OK;
+}
+
+// developer aid: smpc_grid_tail's stamps of the last launch, [8 reducers][16] in s_memrealtime ticks (10 ns)
+int smpc_debug_tail_timeline(smpc_ctx* c, unsigned long long* out)
+{
+  if (!c || !out || !c->d_timeline) return SMPC_ERR_INVALID;
+  HIPCK(c, hipSetDevice(c->device));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipMemcpy(out, c->d_timeline + SMPC_TAIL_STAMPS_AT, 8 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SMPC_OK;
 }
 

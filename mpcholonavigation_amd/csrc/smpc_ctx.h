@@ -91,6 +91,7 @@ const RcclApi* rccl();   // smpc_shard.cpp; null when RCCL cannot be loaded
 inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
 constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
 constexpr uint32_t kLaneMaxT = 128;       // T <= 64: 3 x 64 noised controls parked per lane (or re-read); T <= 128: re-read
+constexpr uint32_t kPollWords = 32;     // completion words behind h_out[3T + 8] (T = 256: 25 blocks of smpc_reduce_partials)
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
                                            // 0.05 m around the robot; the rest is read from HBM/L2
@@ -202,7 +203,10 @@ struct smpc_ctx {
   float* d_out = nullptr;       // [3T u][8 result]
   float* h_out = nullptr;       // pinned, device-mapped: kernels write the result here
   float* h_out_dev = nullptr;   // its device-side address
-  float* d_furthest = nullptr;  // one float (atomicMax on its bits)
+  bool fused_reduce = false;    // SMPC_FUSED_REDUCE=1: smpc_grid_tail reduces inside the scoring launch (an experiment
+                                // that measured no faster than the separate launch: DESIGN.md 4.3)
+  float* d_furthest = nullptr;  // word 0: the furthest point (atomicMax on its bits); 2: smpc_reduce_partials' block count;
+                                // 3: the mailbox exchange's state; 4: smpc_grid_tail's block count
   // launch geometry
   int R = 1;
   uint32_t grid = 0;
@@ -249,6 +253,7 @@ struct smpc_ctx {
   float acker_r = -1.f;      // Ackermann min_turning_r, < 0 for the other models
   uint32_t acker_seq = 0;    // completion word the Ackermann launch publishes this tick
   uint32_t seq = 0, poll_seq = 0;
+  uint32_t poll_words = 0;   // > 0: the tick's completion arrives as this many words (smpc_tail.h), h_out[3T + 8 ...]
   std::string err;
 };
 

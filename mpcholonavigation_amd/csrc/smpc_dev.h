@@ -36,6 +36,17 @@ struct SmpcLut {  // per 8-bit cost: {margin - d | 0, R_infl - d | 0}  (obstacle
   float rep;         // margin - d is always > 0
 };
 
+// optional finishing step of smpc_reduce_partials (single tuple -> new control sequence)
+struct SmpcFinal {
+  int enabled;
+  float vx_max, vx_min, vy_max, wz_max;   // current constraints
+  float* u_dev;                            // [3T + 8] device copy (next iteration reads u here)
+  float* u_host;                           // [3T + 8] host-mapped copy (no D2H memcpy)
+  const float* furthest_used;              // device float or null
+  uint32_t* done_counter;                  // device word, zero between launches
+  uint32_t seq;                            // tick sequence number published at u_host[3T+7]
+};
+
 struct SmpcDev {
   // sizes
   uint32_t B, T, P;
@@ -130,6 +141,12 @@ struct SmpcDev {
   // outputs
   float* partials;         // [gridDim.x][4 + 3T] per-block softmax partials
   uint32_t* furthest_out;  // atomicMax target of the furthest-only pass (float bits)
+  // The reduction of the grid's partials inside the scoring launch (smpc_tail.h): the block that
+  // finishes last reduces them — no second launch, no dependency gap in front of it.
+  uint32_t tail;            // 1: on (the host sets it for grids of at most SMPC_TAIL_MAX_GRID blocks)
+  uint32_t* tail_counter;   // device word, zero between launches
+  float* tuple;             // [4 + 3T] the shard tuple {min, sum w, furthest, non-colliding, U[3T]}
+  SmpcFinal fin;            // single-GPU tick: finish the control sequence and publish it to the host
   // developer aid (SMPC_LANE_TIMELINE=1): [gridDim.x][8] shader-clock stamps of the lane pass
   unsigned long long* timeline;
   // The tick block INSIDE the kernel arguments (small ticks: T <= 64, P <= 64).  The per-tick
@@ -148,6 +165,12 @@ struct SmpcDev {
   float u_arg[3 * 64] __attribute__((aligned(16)));
 };
 #define SMPC_INLINE_TICK_CAP 1536u
+#define SMPC_TAIL_MAX_GRID 512u
+#define SMPC_TAIL_STAMPS_AT (8192u + 2048u * 8u)   /* behind the lane pass's stamps in SmpcDev::timeline */
+// LDS floats smpc_grid_tail works in (from offset 0 of the launch's dynamic LDS, which the pass
+// no longer needs by then): 512 rescale factors, 4 x 16 wave results, [32][64] slice sums per 64 tuple
+// columns, a flag
+static inline uint32_t smpc_tail_lds_bytes(uint32_t T) {return (512u + 64u + ((4u + 3u * T + 63u) / 64u) * 2048u + 4u) * 4u;}
 
 #if defined(__HIPCC__)
 // where a kernel whose FIRST parameter is the SmpcDev finds the tick block (see tick_inline)
@@ -199,16 +222,6 @@ __host__ __device__
 #endif
 static inline uint32_t smpc_furthest_index(float F) {return (uint32_t)(F + 0.5f);}
 
-// optional finishing step of smpc_reduce_partials (single tuple -> new control sequence)
-struct SmpcFinal {
-  int enabled;
-  float vx_max, vx_min, vy_max, wz_max;   // current constraints
-  float* u_dev;                            // [3T + 8] device copy (next iteration reads u here)
-  float* u_host;                           // [3T + 8] host-mapped copy (no D2H memcpy)
-  const float* furthest_used;              // device float or null
-  uint32_t* done_counter;                  // device word, zero between launches
-  uint32_t seq;                            // tick sequence number published at u_host[3T+7]
-};
 
 // mailboxes of the collective-free shard exchange (smpc_p2p_exchange)
 #define SMPC_P2P_MAX_RANKS 16

@@ -31,6 +31,7 @@
 
 #include "smpc_dev.h"
 #include "smpc_device_math.h"
+#include "smpc_tail.h"
 
 #define WAVE 64
 #define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
@@ -949,9 +950,12 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
         acc += sc * allp[(size_t)w * L.scr_stride + i];
       }
     }
-    outp[i] = acc;
+    smpc_store_partial(outp + i, acc);
   }
   stamp(6);
+  if constexpr (!MANY && !RR) {   // (the re-read form's grid is three blocks per CU: over SMPC_TAIL_MAX_GRID)
+    if (p.tail) smpc_grid_tail<(RR ? LANE_BLOCK_RR : LANE_BLOCK) / 64>(p, smem);
+  }
 }
 
 // rr: the re-read instances (no parked controls; required for T > 64; ObstaclesCritic scored)

@@ -357,3 +357,44 @@ def test_costmap_handoff_uploads_only_what_changed(B, T, M):
     assert g.costmap_upload_bytes()[0] == small.size
     with pytest.raises(RuntimeError, match="region outside"):
         g.update_costmap_region(cells, M // 2 - 2, 0, 4, 4)
+
+
+@pytest.mark.parametrize("B,T,flags,speculate", [
+    (1000, 30, 0, True),                              # configs[0]: wave-per-rollout pass, ragged T
+    (2000, 56, 0, True),                              # the deployed shape
+    (2000, 56, 0, False),                             # two-pass mode: furthest-only pass, then scoring
+    (4096, 64, A.SMPC_FLAG_LANE_PER_ROLLOUT, True),   # lane pass, 8 blocks
+    (65536, 64, 0, True),                             # configs[1]: lane pass, 128 blocks
+    (262144, 64, 0, True),                            # the 8-GPU share: 256 blocks
+])
+def test_fused_reduction_matches_the_launch(B, T, flags, speculate, monkeypatch):
+    """The reduction inside the scoring launch (smpc_tail.h: the blocks that finish last reduce the
+    grid's partials; opt-in, SMPC_FUSED_REDUCE=1) against the separate smpc_reduce_partials launch:
+    the same additions in the same order, so every tick agrees bit for bit — control sequence,
+    minimum cost, sum of weights, furthest point, collision count — over a closed loop."""
+    from mpcholonavigation_amd.optimizer import Smpc
+    if not speculate:
+        flags |= A.SMPC_FLAG_NO_SPECULATION
+    cfg = default_config(batch_size=B, time_steps=T, flags=flags)
+    scn = make_scenario(T)
+    noise = make_noise(B, T, seed=5)
+    separate = Smpc(cfg)
+    monkeypatch.setenv("SMPC_FUSED_REDUCE", "1")      # (read when the context is created)
+    fused = Smpc(cfg)
+    monkeypatch.delenv("SMPC_FUSED_REDUCE")
+    for g in (separate, fused):
+        configure(g, scn, noise=noise)
+    us = uf = scn.u0
+    for k in range(4):
+        t = scn.tick
+        tk = Tick(t.pose_x + 0.015 * k, t.pose_y, t.pose_yaw, (0.3, 0.0, 0.0), t.path_x, t.path_y, t.path_yaw,
+                  t.goal_x, t.goal_y)
+        us, os_ = separate.optimize(tk, us)
+        uf, of = fused.optimize(tk, uf)
+        assert np.array_equal(us, uf), k
+        for f in ("min_cost", "sum_w", "furthest_reached_path_point", "non_colliding", "passes", "pass_kind"):
+            assert getattr(os_, f) == getattr(of, f), (k, f)
+        us = np.concatenate([us[:, 1:], us[:, -1:]], axis=1)
+        uf = np.concatenate([uf[:, 1:], uf[:, -1:]], axis=1)
+    separate.close()
+    fused.close()
