@@ -126,7 +126,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   // The block that finishes last reduces the partials inside the scoring launch (smpc_tail.h);
   // larger grids, and launches whose LDS was not sized for it, take the separate reduction.
   if (c->poll_words > kPollWords) return fail(c, SMPC_ERR_UNSUPPORTED, "time_steps beyond the completion words");
-  const bool tail = c->fused_reduce && nblk <= SMPC_TAIL_MAX_GRID &&
+  const bool tail = c->fused_reduce && nblk <= SMPC_TAIL_MAX_GRID && (!lane || c->lane_block == smpc_lane_block()) &&
     (lane ? c->lds_tpr.total : c->lds.total) >= smpc_tail_lds_bytes(d.T);
   // completion words: one per block of smpc_reduce_partials, or per reducing block of the tail
   c->poll_words = (fin.enabled && fin.done_counter) ? (4u + 3u * d.T + 31u) / 32u : 0u;
@@ -140,7 +140,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   }
   // the lane-per-rollout pass scores with the full lean critic stack only
   if (lane) {
-    HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->lane_rr, c->stream));
+    HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->lane_rr, c->lane_block, c->stream));
     c->last_pass_kind = 1;
   } else {
     c->last_pass_kind = 0;
@@ -479,6 +479,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipHostMalloc(&c->h_out, (3 * T + 8 + kPollWords) * sizeof(float), hipHostMallocMapped));
   memset(c->h_out, 0, (3 * T + 8 + kPollWords) * sizeof(float));
   CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_out_dev), c->h_out, 0));
+  c->half_blocks = getenv("SMPC_NO_HALF_BLOCKS") == nullptr;
   c->fused_reduce = getenv("SMPC_FUSED_REDUCE") != nullptr;   // (read per context: tests compare the two)
   CK(hipMalloc(&c->d_furthest, 32));
   CK(hipMemset(c->d_furthest, 0, 32));
@@ -709,9 +710,15 @@ int smpc_get_noise(smpc_ctx* c, float* nvx, float* nvy, float* nwz)
 int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick_out* out)
 {
   if (!c || !in || !u_inout) return fail(c, SMPC_ERR_INVALID, "null argument");
+  // developer aid (SMPC_TICK_TIMING=1): where the host's share of a tick goes, printed every 1024 ticks
+  static const bool timing = getenv("SMPC_TICK_TIMING") != nullptr;
+  using clk = std::chrono::steady_clock;
+  clk::time_point t_in, t_prep, t_launch, t_fetch;
+  if (timing) t_in = clk::now();
   HIPCK(c, hipSetDevice(c->device));
   int rc = prepare_tick(c, in, u_inout);
   if (rc != SMPC_OK) return rc;
+  if (timing) t_prep = clk::now();
   const uint32_t T = c->cfg.time_steps;
   const uint32_t iS = 3 * T + 2, iNC = 3 * T + 3, iSused = 3 * T + 4;
   c->passes = 0;
@@ -755,6 +762,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     rc = launch_score(c, flags, u_dev, dF, hintS, c->d_tuple, true, dF);
     if (rc != SMPC_OK) return rc;
     if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev1, c->stream));
+    if (timing && it == 0) t_launch = clk::now();
     fetched = false;
     const bool last = it + 1 == c->cfg.iteration_count;
     if ((flags & (SD_OBSTACLES | SD_COST)) || spec_try || last) {
@@ -764,6 +772,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
       if (rc != SMPC_OK) return rc;
       fetched = true;
     }
+    if (timing && it == 0) t_fetch = clk::now();
     if (fetched && dF) {
       F_host = c->h_out[iSused];
       S_host = smpc_furthest_index(F_host);
@@ -821,6 +830,25 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     }
     out->score_pass_ms = profile_pass_ms(c);
     out->pass_kind = c->last_pass_kind;
+  }
+  if (timing) {
+    static double acc[5] = {0, 0, 0, 0, 0};
+    static unsigned n = 0;
+    static clk::time_point t_prev_out;
+    const auto t_out = clk::now();
+    auto us = [](clk::time_point a, clk::time_point b) {return std::chrono::duration<double, std::micro>(b - a).count();};
+    if (n > 0) acc[0] += us(t_prev_out, t_in);   // the caller, between two ticks
+    acc[1] += us(t_in, t_prep);
+    acc[2] += us(t_prep, t_launch);
+    acc[3] += us(t_launch, t_fetch);
+    acc[4] += us(t_fetch, t_out);
+    t_prev_out = t_out;
+    if (++n == 1024) {
+      fprintf(stderr, "[smpc tick timing] caller %.2f us, prepare + upload %.2f, launches %.2f, wait %.2f, collect %.2f (per tick, %u ticks)\n",
+              acc[0] / (n - 1), acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, n);
+      n = 0;
+      for (double& a : acc) a = 0;
+    }
   }
   return SMPC_OK;
 }

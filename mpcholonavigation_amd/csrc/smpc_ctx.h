@@ -54,7 +54,7 @@ hipError_t smpc_launch_p2p_exchange(const float* my_tuple, const SmpcP2P& x, uin
                                     hipStream_t st);
 
 hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
-hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, hipStream_t st);
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, uint32_t block, hipStream_t st);
 uint32_t smpc_lane_block();
 uint32_t smpc_lane_block_rr();
 hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu);
@@ -62,7 +62,7 @@ hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_pe
 hipError_t smpc_lane_set_lds_limit(int bytes);
 hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
 hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
-                                      const SmpcLds& L, uint32_t grid, hipStream_t st);
+                                      const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
                                    float neg_inv_temp, hipStream_t st);
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
@@ -174,6 +174,8 @@ struct smpc_ctx {
   bool p2p_failed = false;           // an exchange timed out: no further mailbox tick until re-init
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
+  uint32_t lane_block = 0;      // threads per block of the lane pass this tick
+  bool half_blocks = true;      // (SMPC_NO_HALF_BLOCKS, read when the context is created: experiments)
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
   float* d_costs[2] = {nullptr, nullptr};
   float* d_traj[3] = {nullptr, nullptr, nullptr};

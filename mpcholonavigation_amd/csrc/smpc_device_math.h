@@ -75,6 +75,35 @@ __device__ __forceinline__ void smpc_sincos_fast(float x, float& sn, float& cs)
 #ifndef SMPC_X_MAGIC
 #define SMPC_X_MAGIC 1
 #endif
+#ifndef SMPC_X_HWSIN
+#define SMPC_X_HWSIN 0
+#endif
+  // SMPC_X_HWSIN: measured and rejected (tools/ubench/sincos_hw.hip, tools/variants.sh).  The
+  // hardware's v_sin_f32 / v_cos_f32 on x / 2pi are 3 instructions instead of 20, but quarter
+  // rate: the lane pass gains 4-6 % (60.5 -> 57.0 us, 394.6 -> 377.5 us) and the absolute error
+  // grows from 1.3e-7 to 3.5e-7 for |yaw| <= pi, 7.3e-7 at 8 rad (the float product x / 2pi);
+  // reducing by pi first (form 2) keeps 2e-7 and gains 2-4 %.  Not worth three times the
+  // distance to the reference's libm.
+#if SMPC_X_HWSIN == 1
+  // experiment: the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions)
+  const float t = x * 0.15915494309189535f;
+  sn = __builtin_amdgcn_sinf(t);
+  cs = __builtin_amdgcn_cosf(t);
+  return;
+#elif SMPC_X_HWSIN == 2
+  // experiment: reduce by pi first (exactly), then the hardware on |r| <= pi/2
+  {
+    const float kf = fmaf(x, 0.31830987334251404f, 12582912.0f);
+    const float k = kf - 12582912.0f;
+    float r = fmaf(-k, 3.1415927410125732f, x);
+    r = fmaf(-k, -8.742277657347586e-08f, r);
+    const float t = r * 0.15915494309189535f;
+    const uint32_t sign = __float_as_uint(kf) << 31;
+    sn = __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(t)) ^ sign);
+    cs = __uint_as_float(__float_as_uint(__builtin_amdgcn_cosf(t)) ^ sign);
+    return;
+  }
+#endif
 #if SMPC_X_MAGIC
   const float kf = fmaf(x, 0.31830987334251404f, 12582912.0f);
   const float k = kf - 12582912.0f;

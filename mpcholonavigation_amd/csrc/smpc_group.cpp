@@ -127,7 +127,8 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     if (i == 0) {
       window_bytes = c->lane_window_bytes;
       obst = (flags[i] & SD_OBSTACLES) != 0;
-    } else if (c->lane_window_bytes != window_bytes || ((flags[i] & SD_OBSTACLES) != 0) != obst) {
+    } else if (c->lane_window_bytes != window_bytes || ((flags[i] & SD_OBSTACLES) != 0) != obst ||
+               c->lane_block != c0->lane_block) {
       batched = false;
     }
     Pmax = std::max(Pmax, c->P);
@@ -164,7 +165,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
   }
   HIPCK(c0, hipMemcpyAsync(g->d_all, g->h_all, g->total, hipMemcpyHostToDevice, g->stream));
   HIPCK(c0, smpc_launch_pass_lane_many(reinterpret_cast<const SmpcDev*>(g->d_all + g->off_dev), n,
-                                       T == 64, obst, L, gridx, g->stream));
+                                       T == 64, obst, L, gridx, c0->lane_block, g->stream));
   HIPCK(c0, smpc_launch_reduce_many(reinterpret_cast<const SmpcReduceArgs*>(g->d_all + g->off_red), n,
                                     T, c0->dev.neg_inv_temp, g->stream));
   g->batched_ticks++;

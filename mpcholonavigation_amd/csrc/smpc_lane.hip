@@ -34,6 +34,9 @@
 #include "smpc_tail.h"
 
 #define WAVE 64
+#ifndef LANE_X_RR_NOLOAD
+#define LANE_X_RR_NOLOAD 0   // timing experiment: the re-read form without its second read (wrong results)
+#endif
 #define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
 #define LANE_BLOCK_RR 256   // the re-read instances: 4 waves, three blocks per CU
 
@@ -270,7 +273,8 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // PathAlign's view of the path: {x, y, segment valid ? 1 : 0, 0} per point, one 16-byte read
   f32x4* s_pts4 = reinterpret_cast<f32x4*>(smem + L.off_pts4);
 
-  constexpr int BLK = RR ? LANE_BLOCK_RR : LANE_BLOCK;
+  constexpr int BLK = RR ? LANE_BLOCK_RR : LANE_BLOCK;   // the largest block; small batches launch half of it
+  const int blk = blockDim.x;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -301,7 +305,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     uint32_t tmp[kAhead];
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
-      const int i = tid + k * BLK;
+      const int i = tid + k * blk;
       tmp[k] = i < n4 ? word(i) : 0u;
     }
     const SmpcLut lut_e = (OBST && tid < 256) ? p.lut[tid] : SmpcLut{0.f, 0.f};
@@ -313,10 +317,10 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     if (OBST) {
 #pragma unroll
       for (int k = 0; k < kAhead; ++k) {
-        const int i = tid + k * BLK;
+        const int i = tid + k * blk;
         if (i < n4) reinterpret_cast<uint32_t*>(s_map)[i] = tmp[k];
       }
-      for (int i = tid + kAhead * BLK; i < n4; i += BLK)
+      for (int i = tid + kAhead * blk; i < n4; i += blk)
         reinterpret_cast<uint32_t*>(s_map)[i] = word(i);
       if (!vec) {
         for (int i = tid; i < ww * wh; i += blockDim.x) {
@@ -338,7 +342,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       if (seg_on) s_D[tid] = g_D;
       s_pts4[tid] = f32x4{g_px, g_py, g_valid ? 1.0f : 0.f, 0.f};
     }
-    for (uint32_t i = tid + BLK; i < p.P; i += BLK) {   // paths beyond one point per thread
+    for (uint32_t i = tid + blk; i < p.P; i += blk) {   // paths beyond one point per thread
       const float qx = tk.px[i], qy = tk.py[i];
       const bool seg = i + 1 < p.P;
       s_px[i] = qx;
@@ -846,7 +850,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
           // with its add and waits for each in turn: 192 memory round trips per group)
           float V[64];
 #pragma unroll
-          for (int t = 0; t < 64; ++t) V[t] = ld(ctrl, 64u * h + t);
+          for (int t = 0; t < 64; ++t) V[t] = LANE_X_RR_NOLOAD ? (float)t : ld(ctrl, 64u * h + t);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < 64; ++t) {
@@ -954,13 +958,16 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   }
   stamp(6);
   if constexpr (!MANY && !RR) {   // (the re-read form's grid is three blocks per CU: over SMPC_TAIL_MAX_GRID)
-    if (p.tail) smpc_grid_tail<(RR ? LANE_BLOCK_RR : LANE_BLOCK) / 64>(p, smem);
+    if (p.tail) smpc_grid_tail<(RR ? LANE_BLOCK_RR : LANE_BLOCK) / 64>(p, smem);   // (the host: full-size blocks only)
   }
 }
 
 // rr: the re-read instances (no parked controls; required for T > 64; ObstaclesCritic scored)
-hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, hipStream_t st)
+// block: threads per block of the parking form — LANE_BLOCK, or LANE_BLOCK / 2 for batches of at
+// most one group per SIMD (a wave alone on its SIMD runs a group in 2/3 of the time)
+hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, uint32_t block, hipStream_t st)
 {
+  if (!rr && block != LANE_BLOCK && block != LANE_BLOCK / 2) return hipErrorInvalidValue;
   const bool obst = (p.flags & SD_OBSTACLES) != 0;
   if (rr) {
     // whole chunks only (T = 64 or 128): the ragged instances spill registers, and a spill in
@@ -976,7 +983,7 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
   }
   const bool full = p.T == 64u;
 #define SMPC_LANE_LAUNCH(F, O) \
-  hipLaunchKernelGGL((smpc_pass_lane<F, O, false, 1, false>), dim3(grid), dim3(LANE_BLOCK), L.total, st, p, L, \
+  hipLaunchKernelGGL((smpc_pass_lane<F, O, false, 1, false>), dim3(grid), dim3(block), L.total, st, p, L, \
                      static_cast<const SmpcDev*>(nullptr))
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
@@ -989,11 +996,12 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
 // n planning instances (same T, same critic set) in one launch; d_many: their parameter
 // blocks in device memory
 hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
-                                      const SmpcLds& L, uint32_t grid, hipStream_t st)
+                                      const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st)
 {
+  if (block != LANE_BLOCK && block != LANE_BLOCK / 2) return hipErrorInvalidValue;
   const SmpcDev none{};
 #define SMPC_LANE_LAUNCH(F, O) \
-  hipLaunchKernelGGL((smpc_pass_lane<F, O, true, 1, false>), dim3(grid, n), dim3(LANE_BLOCK), L.total, st, none, L, \
+  hipLaunchKernelGGL((smpc_pass_lane<F, O, true, 1, false>), dim3(grid, n), dim3(block), L.total, st, none, L, \
                      d_many)
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);

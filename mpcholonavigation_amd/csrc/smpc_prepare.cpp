@@ -409,9 +409,20 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
       c->occ_tpr_blocks = static_cast<uint32_t>(nb);
       c->occ_tpr_lds = occ_key;
     }
-    const uint32_t groups = (B + 63) / 64, wpb = lblock / 64;
+    const uint32_t groups = (B + 63) / 64;
+    uint32_t wpb = lblock / 64;
+    c->lane_block = lblock;
+    // Small batches: when every group can have a SIMD to itself (at most four groups per CU),
+    // blocks of four waves, one per CU.  Two waves on a SIMD share its VALU and each runs its
+    // group in 22.5 us; a wave alone runs it in 20.5 (tools/lane_timeline.py) — and a batch
+    // this small is one group per wave anyway: -2 us per tick at 65 536 x 64.
+    if (!c->lane_rr && c->half_blocks && groups <= static_cast<uint32_t>(c->num_cu) * 4u) {
+      wpb = 4;
+      c->lane_block = 256;
+    }
     uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
-    c->grid_tpr = std::max(1u, std::min(g, kMaxGrid));
+    g = std::max(1u, std::min(g, kMaxGrid));
+    c->grid_tpr = g;
     // window-relative float cell index and its guard band.  The pass forms
     //   q~ = fma(ax, (1/res)_f, cxf),   cxf = ((x0 - window corner) / res)_f
     // from the accumulated displacement ax; the reference truncates

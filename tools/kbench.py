@@ -13,7 +13,8 @@ from oracle.loader import Oracle, build
 
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 build()
-for (B, T, M) in ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000), (4096, 128, 2000), (8192, 128, 200)):
+PARITY = () if os.environ.get("KBENCH_NO_PARITY") else ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000), (4096, 128, 2000), (8192, 128, 200))
+for (B, T, M) in PARITY:
     cfg, scn, noise = make_case(B, T, map_size=M)
     cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
     g, o = Smpc(cfg), Oracle(cfg)
@@ -26,7 +27,8 @@ for (B, T, M) in ((16384, 64, 200), (8192, 40, 200), (4096, 64, 2000), (4096, 12
     g.close()
 
 import torch
-for (B, T, M) in ((262144, 64, 200), (2097152, 64, 200), (262144, 128, 2000)):
+SIZES = [tuple(int(v) for v in s.split("x")) for s in os.environ["KBENCH_SIZES"].split(",")] if os.environ.get("KBENCH_SIZES") else [(262144, 64, 200), (2097152, 64, 200), (262144, 128, 2000)]
+for (B, T, M) in SIZES:
     g, scn, cfg = make_ctx(B, T, M)
     u = scn.u0
     for _ in range(5):
