@@ -11,7 +11,9 @@ from bench import make_ctx, shift
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 GHZ = float(sys.argv[2]) if len(sys.argv) > 2 else 2.2
-g, scn, cfg = make_ctx(B, 64, 200)
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+M = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+g, scn, cfg = make_ctx(B, T, M)
 u = scn.u0
 for _ in range(5):
     u_new, out = g.optimize(scn.tick, u)
