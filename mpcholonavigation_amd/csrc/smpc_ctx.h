@@ -175,6 +175,7 @@ struct smpc_ctx {
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
   uint32_t lane_block = 0;      // threads per block of the lane pass this tick
+  bool in_group = false;        // member of an smpc_group: full-size blocks always (the group fills the CUs by itself)
   bool half_blocks = true;      // (SMPC_NO_HALF_BLOCKS, read when the context is created: experiments)
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
   float* d_costs[2] = {nullptr, nullptr};

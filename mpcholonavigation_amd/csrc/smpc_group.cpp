@@ -58,6 +58,7 @@ int smpc_group_create(smpc_ctx* const* ctxs, uint32_t n, smpc_group** out)
     c->h_tick = g->h_all + g->slot * i;
     c->d_tick = g->d_all + g->slot * i;
     c->defer_upload = true;
+    c->in_group = true;
     c->lut_valid = false;
   }
   *out = g;
@@ -74,6 +75,7 @@ void smpc_group_destroy(smpc_group* g)
     c->h_tick = g->saved_h_tick[i];
     c->d_tick = g->saved_d_tick[i];
     c->defer_upload = false;
+    c->in_group = false;
   }
   if (g->h_all) (void)hipHostFree(g->h_all);
   if (g->d_all) (void)hipFree(g->d_all);

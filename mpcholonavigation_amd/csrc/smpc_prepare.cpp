@@ -416,7 +416,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     // blocks of four waves, one per CU.  Two waves on a SIMD share its VALU and each runs its
     // group in 22.5 us; a wave alone runs it in 20.5 (tools/lane_timeline.py) — and a batch
     // this small is one group per wave anyway: -2 us per tick at 65 536 x 64.
-    if (!c->lane_rr && c->half_blocks && groups <= static_cast<uint32_t>(c->num_cu) * 4u) {
+    if (!c->lane_rr && c->half_blocks && !c->in_group && groups <= static_cast<uint32_t>(c->num_cu) * 4u) {
       wpb = 4;
       c->lane_block = 256;
     }
