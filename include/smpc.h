@@ -439,6 +439,14 @@ uint32_t smpc_tuple_len(const smpc_ctx* ctx);
 
 /* Upload the tick's inputs and control sequence (host pointers). */
 int smpc_shard_begin(smpc_ctx* ctx, const smpc_tick_in* in, const float* u_in);
+/* The furthest reached path point this tick is expected to have: the previous tick's value
+ * (as smpc_shard_combine saw it) carried forward by the robot's motion, the plan's pruning and
+ * the last tick's drift — what smpc_optimize and smpc_shard_tick speculate with.  Returns 1 and
+ * writes *hint when there is a prediction (smpc_shard_begin of this tick has run and an
+ * earlier tick's smpc_shard_combine reported a furthest point), else 0.  Every rank computes
+ * the same value from the same inputs.  Scoring with it is exact either way: the combined
+ * tuple reports the true value and a caller that finds a mismatch scores again. */
+int smpc_shard_predicted_furthest(smpc_ctx* ctx, uint32_t* hint);
 /* Local max over this shard of the nearest-path-point index of each rollout's
  * endpoint [ref tools/utils.hpp:292-319], written as one float to d_furthest. */
 int smpc_shard_furthest(smpc_ctx* ctx, float* d_furthest);

@@ -266,6 +266,7 @@ PROTOTYPES = {
     "smpc_tuple_len": (C.c_uint32, [_ctx]),
     "smpc_shard_begin": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p]),
     "smpc_shard_furthest": (C.c_int, [_ctx, C.c_void_p]),
+    "smpc_shard_predicted_furthest": (C.c_int, [_ctx, C.POINTER(C.c_uint32)]),
     "smpc_shard_score": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p]),
     "smpc_shard_rescore_failed": (C.c_int, [_ctx, C.c_void_p]),
     "smpc_shard_combine": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_void_p,

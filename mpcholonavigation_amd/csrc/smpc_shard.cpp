@@ -49,7 +49,18 @@ int smpc_shard_begin(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   c->passes = 0;
   c->evp_used = 0;
   c->costs_cur = 0;
+  // (the caller keeps *in and its arrays alive until the tick's last smpc_shard_combine)
+  c->step_in = *in;
+  c->step_remembered = false;
   return prepare_tick(c, in, u_in);
+}
+
+int smpc_shard_predicted_furthest(smpc_ctx* c, uint32_t* hint)
+{
+  if (!c || !hint) return 0;
+  if (!c->tick_ready || !c->hint_valid || !(c->gate_flags & SD_NEED_FURTHEST)) return 0;
+  *hint = c->hint;
+  return 1;
 }
 
 int smpc_shard_furthest(smpc_ctx* c, float* d_furthest)
@@ -90,6 +101,11 @@ int smpc_shard_combine(smpc_ctx* c, const float* d_tuples, uint32_t n_tuples, fl
   if (rc != SMPC_OK) return rc;
   const uint32_t T = c->cfg.time_steps;
   memcpy(u_out, c->h_out, 3 * T * sizeof(float));
+  // the predictor's state advances once per tick (a re-scored tick combines twice: same value)
+  if ((c->gate_flags & SD_NEED_FURTHEST) && !c->step_remembered) {
+    remember_furthest(c, &c->step_in, c->h_out[3 * T + 2]);
+    c->step_remembered = true;
+  }
   if (out) {
     memset(out, 0, sizeof(*out));
     const bool obstacles_scored = (scoring_flags(c, c->fail_in) & (SD_OBSTACLES | SD_COST)) != 0;

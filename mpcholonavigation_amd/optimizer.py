@@ -197,6 +197,11 @@ class Smpc:
         u = np.ascontiguousarray(u, dtype=np.float32)
         self._ck(self.lib.smpc_shard_begin(self.h, C.byref(tick.c), _ptr(u)))
 
+    def shard_predicted_furthest(self):
+        """The index this tick is expected to have (after shard_begin), or None."""
+        h = C.c_uint32(0)
+        return int(h.value) if self.lib.smpc_shard_predicted_furthest(self.h, C.byref(h)) else None
+
     def shard_furthest(self, d_furthest):
         self._ck(self.lib.smpc_shard_furthest(self.h, C.c_void_p(d_furthest)))
 

@@ -41,6 +41,9 @@ class HipShard:
     def begin(self, tick, u):
         self.smpc.shard_begin(tick, u)
 
+    def predicted_furthest(self):
+        return self.smpc.shard_predicted_furthest()
+
     def furthest(self, t_furthest):
         self.smpc.shard_furthest(t_furthest.data_ptr())
 
@@ -154,6 +157,12 @@ class ShardedOptimizer:
         b = self.b
         b.begin(tick, u)
         if self.speculate and self.hint is not None:
+            # the library's prediction of this tick's index (previous value carried forward by the
+            # robot's motion and the plan's pruning: the same on every rank) where the backend has one
+            predict = getattr(b, "predicted_furthest", None)
+            p = predict() if predict is not None else None
+            if p is not None:
+                self.hint = p
             b.score(None, self.hint, self.t_tuple)
             self._gather()
             u_new, out = b.combine(self.t_all, self.G)

@@ -85,6 +85,38 @@ def test_sharded_driver_single_rank_gpu():
             uo = u.copy()
 
 
+def test_stepwise_sharded_tick_uses_the_library_prediction():
+    """The step-wise sharded API (smpc_shard_begin / _score / _combine, driven by ShardedOptimizer)
+    speculates with the library's prediction of the furthest point (smpc_shard_predicted_furthest),
+    not with last tick's value: in a closed loop with a moving pose and a pruned plan it re-scores
+    on a few ticks only, and every tick equals what smpc_optimize gives on the same inputs."""
+    from bench import MovingScene, shift
+    from mpcholonavigation_amd.optimizer import Smpc
+    from mpcholonavigation_amd.sharded import HipShard, ShardedOptimizer
+    B, T = 8192, 64
+    scn = make_scenario(T)
+    noise = make_noise(B, T)
+    torch.cuda.set_device(0)
+    cfg = default_config(batch_size=B, time_steps=T)
+    g = _mk(Smpc, cfg, scn, noise, slice(0, B))
+    ref = _mk(Smpc, cfg, scn, noise, slice(0, B))
+    so = ShardedOptimizer(HipShard(g), speculate=True)
+    mv = MovingScene(scn, cfg.model_dt)
+    u = scn.u0
+    n = 30
+    for k in range(n):
+        tk = mv.tick()
+        us, outs = so.optimize(tk, u)
+        ur, outr = ref.optimize(tk, u)
+        assert outs.furthest_reached_path_point == outr.furthest_reached_path_point, k
+        assert outs.non_colliding == outr.non_colliding, k
+        assert rel_err(us, ur) < 2e-6, k          # same kernels, the combine instead of the finishing reduction
+        mv.advance(ur)
+        u = shift(ur)
+    print(f"[stepwise sharded] {so.rescored} re-scored ticks of {n}")
+    assert so.rescored <= 4
+
+
 def test_gpu_shard_rng_is_a_slice_of_the_global_stream():
     from mpcholonavigation_amd.optimizer import Smpc
     B, T = 200, 33
