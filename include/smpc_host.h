@@ -38,6 +38,12 @@ typedef struct sortham_optimizer_config {
 
 int sortham_optimizer_create(const sortham_optimizer_config* cfg, const smpc_critic_params* critics,
                              sortham_optimizer** out);
+/* Optimizer::initialize() again on a live object: what the plugin's reset() does after every
+ * idle period and on a parameter change [ref src/optimizer.cpp:46-60,116-132,
+ * src/controller.cpp:89-92].  An unchanged configuration (shapes, model, sampling, seed) keeps
+ * the device context and only resets state and re-draws the noise; anything else rebuilds it. */
+int sortham_optimizer_initialize(sortham_optimizer* o, const sortham_optimizer_config* cfg,
+                                 const smpc_critic_params* critics);
 void sortham_optimizer_destroy(sortham_optimizer* o);
 const char* sortham_optimizer_last_error(const sortham_optimizer* o);
 

@@ -69,7 +69,16 @@ void Optimizer::initialize(
   double controller_frequency, const CriticsConfig & critics, bool regenerate_noises,
   uint64_t noise_seed, int device)
 {
-  shutdown();
+  // A call with the configuration the device context was built for (the controller's reset()
+  // after every idle period, src/controller.cpp:89-92, re-reads unchanged parameters) keeps the
+  // context: decided below, once the new smpc_config is known.
+  smpc_ctx * keep = ctx_;
+  ctx_ = nullptr;
+  struct Guard
+  {
+    smpc_ctx *& k;
+    ~Guard() {if (k) {smpc_destroy(k);}}   // a throwing initialize() leaves no context behind, as before
+  } guard{keep};
   settings_ = settings;
   settings_.constraints = settings_.base_constraints;
   setMotionModel(motion_model);
@@ -116,6 +125,7 @@ void Optimizer::initialize(
   }
 
   smpc_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));   // (compared byte for byte below: no stray padding)
   smpc_config_default(&cfg);
   cfg.batch_size = settings_.batch_size;
   cfg.time_steps = settings_.time_steps;
@@ -134,10 +144,27 @@ void Optimizer::initialize(
   cfg.wz_std = settings_.sampling_std.wz;
   cfg.device = device_;
   cfg.flags = visualize_ ? SMPC_FLAG_STORE_TRAJECTORIES : 0u;
+  if (keep && have_built_ && std::memcmp(&cfg, &built_cfg_, sizeof(cfg)) == 0 && noise_seed_ == built_seed_) {
+    // same shapes, model, sampling and seed: only the critics' parameters can differ.  What the
+    // reference's reset() does (src/optimizer.cpp:116-132) is reset() below, noise re-draw included.
+    ctx_ = keep;
+    keep = nullptr;
+    ck(ctx_, smpc_set_critics(ctx_, &critics_.params), "smpc_set_critics");
+    reset();
+    return;
+  }
+  if (keep) {
+    smpc_destroy(keep);
+    keep = nullptr;
+  }
+  have_built_ = false;
   int rc = smpc_create(&cfg, &ctx_);
   if (rc != SMPC_OK) {
     throw std::runtime_error(std::string("smpc_create: ") + smpc_last_error(nullptr));
   }
+  built_cfg_ = cfg;
+  built_seed_ = noise_seed_;
+  have_built_ = true;
   ck(ctx_, smpc_set_critics(ctx_, &critics_.params), "smpc_set_critics");
   // NoiseGenerator::initialize draws once (noise_generator.cpp:26-42) ...
   ck(ctx_, smpc_seed(ctx_, noise_seed_), "smpc_seed");

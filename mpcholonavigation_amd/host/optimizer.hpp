@@ -187,6 +187,9 @@ protected:
   bool supplied_noise_{false};
   int device_{-1};
   smpc_ctx * ctx_{nullptr};
+  smpc_config built_cfg_{};     // what ctx_ was created with (initialize() keeps it for an identical one)
+  uint64_t built_seed_{0};
+  bool have_built_{false};
 
   // per-tick (CriticData)
   Pose2D pose_{}, goal_{};

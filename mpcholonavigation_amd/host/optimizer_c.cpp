@@ -36,6 +36,36 @@ int guarded(sortham_optimizer * o, F && f)
 }
 }  // namespace
 
+namespace {
+// the parameter reads of the plugin's Optimizer::getParams() + reset() (nav2_plugin/src/optimizer.cpp)
+void initialize_from(sortham_optimizer * o, const sortham_optimizer_config * cfg, const smpc_critic_params * critics)
+{
+  sortham_ns::models::OptimizerSettings s;
+  const smpc_config & b = cfg->base;
+  s.base_constraints = {b.vx_max, b.vx_min, b.vy_max, b.wz_max};
+  s.sampling_std = {b.vx_std, b.vy_std, b.wz_std};
+  s.model_dt = b.model_dt;
+  s.temperature = b.temperature;
+  s.gamma = b.gamma;
+  s.batch_size = b.batch_size;
+  s.time_steps = b.time_steps;
+  s.iteration_count = b.iteration_count;
+  s.retry_attempt_limit = cfg->retry_attempt_limit;
+  sortham_ns::CriticsConfig cc;
+  cc.params = *critics;
+  for (uint32_t i = 0; i < cfg->n_critics && i < 16; ++i) {
+    cc.critics.emplace_back(cfg->critics[i] ? cfg->critics[i] : "");
+  }
+  cc.cost_scaling_factor = cfg->cost_scaling_factor;
+  cc.inflation_radius = cfg->inflation_radius;
+  o->opt.setVisualize(cfg->visualize != 0);
+  o->opt.setAckermannMinTurningRadius(b.ackermann_min_turning_r);
+  o->opt.initialize(
+    s, cfg->motion_model ? cfg->motion_model : "DiffDrive", cfg->controller_frequency, cc,
+    cfg->regenerate_noises != 0, cfg->noise_seed, b.device);
+}
+}  // namespace
+
 extern "C" {
 
 int sortham_optimizer_create(
@@ -50,38 +80,22 @@ int sortham_optimizer_create(
   if (!o) {
     return SMPC_ERR_NOMEM;
   }
-  int rc = guarded(
-    nullptr, [&]() {
-      sortham_ns::models::OptimizerSettings s;
-      const smpc_config & b = cfg->base;
-      s.base_constraints = {b.vx_max, b.vx_min, b.vy_max, b.wz_max};
-      s.sampling_std = {b.vx_std, b.vy_std, b.wz_std};
-      s.model_dt = b.model_dt;
-      s.temperature = b.temperature;
-      s.gamma = b.gamma;
-      s.batch_size = b.batch_size;
-      s.time_steps = b.time_steps;
-      s.iteration_count = b.iteration_count;
-      s.retry_attempt_limit = cfg->retry_attempt_limit;
-      sortham_ns::CriticsConfig cc;
-      cc.params = *critics;
-      for (uint32_t i = 0; i < cfg->n_critics && i < 16; ++i) {
-        cc.critics.emplace_back(cfg->critics[i] ? cfg->critics[i] : "");
-      }
-      cc.cost_scaling_factor = cfg->cost_scaling_factor;
-      cc.inflation_radius = cfg->inflation_radius;
-      o->opt.setVisualize(cfg->visualize != 0);
-      o->opt.setAckermannMinTurningRadius(b.ackermann_min_turning_r);
-      o->opt.initialize(
-        s, cfg->motion_model ? cfg->motion_model : "DiffDrive", cfg->controller_frequency, cc,
-        cfg->regenerate_noises != 0, cfg->noise_seed, b.device);
-    });
+  int rc = guarded(nullptr, [&]() {initialize_from(o, cfg, critics);});
   if (rc != SMPC_OK) {
     delete o;
     return rc;
   }
   *out = o;
   return SMPC_OK;
+}
+
+int sortham_optimizer_initialize(
+  sortham_optimizer * o, const sortham_optimizer_config * cfg, const smpc_critic_params * critics)
+{
+  if (!o || !cfg || !critics) {
+    return SMPC_ERR_INVALID;
+  }
+  return guarded(o, [&]() {initialize_from(o, cfg, critics);});
 }
 
 void sortham_optimizer_destroy(sortham_optimizer * o) {delete o;}

@@ -38,6 +38,8 @@ _ctx = C.c_void_p
 PROTOTYPES = {
     "sortham_optimizer_create": (C.c_int, [C.POINTER(SorthamOptimizerConfig),
                                            C.POINTER(A.SmpcCriticParams), C.POINTER(_ctx)]),
+    "sortham_optimizer_initialize": (C.c_int, [_ctx, C.POINTER(SorthamOptimizerConfig),
+                                               C.POINTER(A.SmpcCriticParams)]),
     "sortham_optimizer_destroy": (None, [_ctx]),
     "sortham_optimizer_last_error": (C.c_char_p, [_ctx]),
     "sortham_optimizer_set_costmap": (C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -78,6 +80,25 @@ class Optimizer:
                  regenerate_noises=False, visualize=False, noise_seed=0,
                  cost_scaling_factor=10.0, inflation_radius=0.55):
         self.lib = load_library()
+        c = self._config(cfg, controller_frequency, critics, motion_model, retry_attempt_limit,
+                         regenerate_noises, visualize, noise_seed, cost_scaling_factor, inflation_radius)
+        h = _ctx()
+        rc = self.lib.sortham_optimizer_create(C.byref(c), C.byref(critic_params), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(self.lib.sortham_optimizer_last_error(None).decode() or f"error {rc}")
+        self.h = h
+
+    def initialize(self, cfg: A.SmpcConfig, critic_params: A.SmpcCriticParams, controller_frequency,
+                   critics=None, motion_model="Omni", retry_attempt_limit=1, regenerate_noises=False,
+                   visualize=False, noise_seed=0, cost_scaling_factor=10.0, inflation_radius=0.55):
+        """Optimizer::initialize() again on the live object (the plugin's reset()): an unchanged
+        configuration keeps the device context, anything else rebuilds it."""
+        c = self._config(cfg, controller_frequency, critics, motion_model, retry_attempt_limit,
+                         regenerate_noises, visualize, noise_seed, cost_scaling_factor, inflation_radius)
+        self._ck(self.lib.sortham_optimizer_initialize(self.h, C.byref(c), C.byref(critic_params)))
+
+    def _config(self, cfg, controller_frequency, critics, motion_model, retry_attempt_limit,
+                regenerate_noises, visualize, noise_seed, cost_scaling_factor, inflation_radius):
         self.T, self.B = cfg.time_steps, cfg.batch_size
         c = SorthamOptimizerConfig()
         c.base = cfg
@@ -92,11 +113,8 @@ class Optimizer:
         c.n_critics = len(names)
         c.cost_scaling_factor, c.inflation_radius = cost_scaling_factor, inflation_radius
         c.motion_model = motion_model.encode()
-        h = _ctx()
-        rc = self.lib.sortham_optimizer_create(C.byref(c), C.byref(critic_params), C.byref(h))
-        if rc != 0:
-            raise RuntimeError(self.lib.sortham_optimizer_last_error(None).decode() or f"error {rc}")
-        self.h = h
+        self._keep = c       # (the name strings stay alive with the struct)
+        return c
 
     def close(self):
         if getattr(self, "h", None):

@@ -57,8 +57,9 @@ void Optimizer::getParams()
 
 void Optimizer::reset()
 {
-  // (re)build the device context from the current parameters, as the reference's reset()
-  // re-allocates its tensors (src/optimizer.cpp:116-132)
+  // the reference's reset() re-allocates its tensors (src/optimizer.cpp:116-132); here
+  // host_.initialize() keeps the device context when the parameters it was built from are
+  // unchanged (the controller resets after every idle period) and rebuilds it otherwise
   std::vector<std::string> names;
   auto getParam = parameters_handler_->getParamGetter(name_);
   getParam(names, "critics", std::vector<std::string>{}, ParameterType::Static);

@@ -163,6 +163,46 @@ def test_speed_limit_and_reset():
     assert np.array_equal(h.get_constraints()[0], c0)
 
 
+def test_initialize_again_keeps_the_device_context_for_an_unchanged_configuration():
+    """The plugin's reset() runs Optimizer::initialize() after every idle period
+    (src/controller.cpp:89-92, src/optimizer.cpp:116-132).  With the configuration the device
+    context was built for it only resets state and re-draws the noise — the costmap that was
+    handed over stays where it is, the next tick needs no new hand-over — and with another batch
+    size it rebuilds the context, which then has no costmap until one is set."""
+    from mpcholonavigation_amd.host_optimizer import Optimizer
+    B, T = 1000, 30
+    cfg = default_config(batch_size=B, time_steps=T)
+    scn = make_scenario(T)
+    h = Optimizer(cfg, default_critics(), 20.0, noise_seed=7)
+    h.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
+    c0, _ = h.get_constraints()
+    for _ in range(3):
+        tw, _ = h.eval_control(scn.tick)
+    assert h.get_control_sequence().any()
+    h.set_speed_limit(50.0, True)
+    # unchanged: light path
+    h.initialize(cfg, default_critics(), 20.0, noise_seed=7)
+    assert not h.get_control_sequence().any()
+    assert np.array_equal(h.get_constraints()[0], c0)
+    tw2, out = h.eval_control(scn.tick)                      # the costmap is still there
+    assert np.isfinite(tw2).all() and out.non_colliding > 0
+    # a changed critic weight travels on the light path too
+    cr = default_critics()
+    cr.path_follow.cost_weight = 50.0
+    h.initialize(cfg, cr, 20.0, noise_seed=7)
+    tw3, _ = h.eval_control(scn.tick)
+    assert np.isfinite(tw3).all()
+    # another batch size: a new context, no costmap yet
+    cfg2 = default_config(batch_size=2 * B, time_steps=T)
+    h.initialize(cfg2, default_critics(), 20.0, noise_seed=7)
+    with pytest.raises(RuntimeError):
+        h.eval_control(scn.tick)
+    h.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
+    tw4, _ = h.eval_control(scn.tick)
+    assert np.isfinite(tw4).all()
+    h.close()
+
+
 @pytest.mark.parametrize("retry", [1, 2])
 def test_fallback_retries_then_throws(retry):
     """Every rollout collides: fallback() resets and retries retry_attempt_limit times, the
