@@ -95,6 +95,7 @@ constexpr uint32_t kPollWords = 32;     // completion words behind h_out[3T + 8]
 constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
                                            // 0.05 m around the robot; the rest is read from HBM/L2
+constexpr uint32_t kWindowSideMax = 144;       // T > 64: up to 144 x 144 cells (20 KB, +-3.6 m at 0.05 m: measured optimum, smpc_prepare.cpp)
 constexpr uint32_t kLdsPerCu = 160 * 1024;
 
 inline uint32_t align_up(uint32_t v, uint32_t a) {return (v + a - 1) / a * a;}

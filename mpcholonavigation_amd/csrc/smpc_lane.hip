@@ -38,7 +38,9 @@
 #define LANE_X_RR_NOLOAD 0   // timing experiment: the re-read form without its second read (wrong results)
 #endif
 #define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
+#ifndef LANE_BLOCK_RR
 #define LANE_BLOCK_RR 256   // the re-read instances: 4 waves, three blocks per CU
+#endif
 
 // experiment switches (tools/variants.sh builds the library with some of them off)
 #ifndef LANE_X_GAMMA_N
@@ -253,7 +255,7 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // the register file's per-wave share: 256-thread blocks, three per CU (three waves per SIMD).
 // The only form for T > 64 (3 T parked values per lane do not fit any register budget).
 template <bool FULL, bool OBST, bool MANY, int NCH, bool RR>
-__global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, RR ? 3 : 1)
+__global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, (RR && LANE_BLOCK_RR == 256) ? 3 : 1)
 smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ many)
 {
   static_assert(RR || NCH == 1, "parked controls: one chunk of 64 steps");

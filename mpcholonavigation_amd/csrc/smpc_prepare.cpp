@@ -332,6 +332,24 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   if (c->map.set && (gates & (SD_OBSTACLES | SD_COST))) {
     uint32_t side = 4;
     while ((side + 4) * (side + 4) <= kWindowBytes) side += 4;   // 96 cells
+    // Long horizons reach further than that: 128 steps of 0.05 s at 0.5 m/s are 3.2 m, and a
+    // rollout outside the window fetches its cells from the global map behind a full memory
+    // wait, inside the time loop (the 262 144 x 128 pass: 183 us with the 96-cell window, 150 us
+    // with 128..144 cells; beyond that the staging of the window by every block costs more than
+    // the stragglers, tools/kbench.py with SMPC_WINDOW_SIDE_MAX).  For T > 64 the window covers
+    // the reach at the largest constrained speed plus four standard deviations of the mean
+    // noise, up to kWindowSideMax cells; the passes that run T > 64 (the re-read form, the
+    // wave-per-rollout pass) have the LDS for it.
+    if (T > 64 && !getenv("SMPC_SMALL_WINDOW")) {
+      const float sigma = std::max(c->cfg.vx_std, c->holonomic ? c->cfg.vy_std : 0.f);
+      const float vmax = std::max(std::max(std::fabs(c->c_vx_max), std::fabs(c->c_vx_min)), std::fabs(c->c_vy)) +
+        4.f * sigma / std::sqrt(static_cast<float>(T));
+      const double reach_cells = static_cast<double>(T) * c->cfg.model_dt * vmax / c->map.res;
+      const uint32_t want = (static_cast<uint32_t>(2.0 * reach_cells) + 8u + 3u) & ~3u;
+      uint32_t side_max = kWindowSideMax;
+      if (const char* e = getenv("SMPC_WINDOW_SIDE_MAX")) side_max = static_cast<uint32_t>(atoi(e)) & ~3u;   // experiments
+      side = std::max(side, std::min(want, side_max));
+    }
     const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
     long cx = static_cast<long>((in->pose_x - c->map.ox) / c->map.res);
     long cy = static_cast<long>((in->pose_y - c->map.oy) / c->map.res);
