@@ -31,6 +31,7 @@ _PROTOTYPES = {
     "smpc_oracle_seed": (C.c_int, [_ctx, C.c_uint64]),
     "smpc_oracle_get_noise": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
     "smpc_oracle_set_accumulate_double": (C.c_int, [_ctx, C.c_int]),
+    "smpc_oracle_set_log_float": (C.c_int, [_ctx, C.c_int]),
     "smpc_oracle_optimize": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), _f32p,
                                        C.POINTER(A.SmpcTickOut)]),
     "smpc_oracle_get_trajectories": (C.c_int, [_ctx, _f32p, _f32p, _f32p]),
@@ -182,6 +183,9 @@ class Oracle:
 
     def set_accumulate_double(self, on):
         self._ck(self.lib.smpc_oracle_set_accumulate_double(self.h, int(on)))
+
+    def set_log_float(self, on):
+        self._ck(self.lib.smpc_oracle_set_log_float(self.h, int(on)))
 
     def optimize(self, tick, u):
         """u: float32 [3, T] (vx, vy, wz); returns (u_new, SmpcTickOut)."""

@@ -370,6 +370,7 @@ struct smpc_oracle {
   uint64_t seed = 0;
   uint32_t epoch = 0;
   bool accumulate_double = false;
+  bool log_float = false;   // distanceToObstacle's log() as the float overload (diagnostic)
   std::vector<float> nvx, nvy, nwz;                // NoiseGenerator::noises_*
   std::vector<float> vx, vy, wz, cvx, cvy, cwz;    // models::State
   std::vector<float> tx, ty, tyaw;                 // models::Trajectories
@@ -772,12 +773,21 @@ void score_obstacles(smpc_oracle * o, const Tick & tk)
       if (cm.inflation_radius == 0.0f || cm.cost_scaling_factor == 0.0f) {
         continue;
       }
-      // distanceToObstacle :99-112 (log() resolves to the double overload)
+      // distanceToObstacle :99-112.  The reference writes an unqualified log(float) after
+      // #include <cmath>: with glibc's math.h that is ::log(double) — the default here — unless
+      // some header of the translation unit pulled in libstdc++'s <math.h> wrapper, whose
+      // using-declarations add ::log(float).  log_float restates that second reading (a
+      // diagnostic: tests bound what the ambiguity can move).
       const float scale_factor = cm.cost_scaling_factor;
       const float min_radius = cm.inscribed_radius;
-      float dist_to_obj = static_cast<float>(
-        (static_cast<double>(scale_factor * min_radius) - std::log(static_cast<double>(cost)) +
-        std::log(static_cast<double>(253.0f))) / static_cast<double>(scale_factor));
+      float dist_to_obj;
+      if (o->log_float) {
+        dist_to_obj = (scale_factor * min_radius - std::log(cost) + std::log(253.0f)) / scale_factor;
+      } else {
+        dist_to_obj = static_cast<float>(
+          (static_cast<double>(scale_factor * min_radius) - std::log(static_cast<double>(cost)) +
+          std::log(static_cast<double>(253.0f))) / static_cast<double>(scale_factor));
+      }
       if (!using_footprint) {
         dist_to_obj -= min_radius;   // :106-108
       }
@@ -1578,6 +1588,13 @@ int smpc_oracle_set_accumulate_double(smpc_oracle * o, int on)
 {
   if (!o) {return SMPC_ERR_INVALID;}
   o->accumulate_double = on != 0;
+  return SMPC_OK;
+}
+
+int smpc_oracle_set_log_float(smpc_oracle * o, int on)
+{
+  if (!o) {return SMPC_ERR_INVALID;}
+  o->log_float = on != 0;
   return SMPC_OK;
 }
 

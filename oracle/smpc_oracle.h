@@ -56,6 +56,11 @@ int smpc_oracle_get_noise(smpc_oracle* o, float* nvx, float* nvy, float* nwz);
  * (diagnostic: separates kernel error from the reference's own float
  * accumulation error at large B).  Default 0 = float like the reference. */
 int smpc_oracle_set_accumulate_double(smpc_oracle* o, int on);
+/* 1: ObstaclesCritic::distanceToObstacle's unqualified log(float) [ref
+ * src/critics/obstacles_critic.cpp:103] evaluated by the float overload instead of the
+ * double one (which of the two the reference's build picks depends on its headers; a
+ * diagnostic that bounds what the ambiguity can move).  Default 0 = double. */
+int smpc_oracle_set_log_float(smpc_oracle* o, int on);
 
 int smpc_oracle_optimize(smpc_oracle* o, const smpc_tick_in* in, float* u_inout,
                          smpc_tick_out* out);
