@@ -257,8 +257,8 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   constexpr bool FURTHEST_ONLY = MODE == 1;
   constexpr bool GENERIC = MODE == 2;
   // MODE 0 is the lean kernel: the rarely used features (trajectory write-out, path
-  // orientations, the near-goal GoalAngle term) live only in MODE 2, so their pointers and
-  // parameters do not occupy scalar registers in the hot loop
+  // orientations) live only in MODE 2, so their pointers and parameters do not occupy scalar
+  // registers in the hot loop; the near-goal GoalAngle term is scored by MODE 3 (power 1) or 2
   constexpr bool RARE = MODE != 0 && MODE != 3;
   constexpr bool EXTRA = MODE == 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -948,6 +948,18 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
     }
 
     if (EXTRA) {
+      if (p.flags & SD_GOAL_ANGLE) {
+        // GoalAngleCritic with cost_power 1 (goal_angle_critic.cpp:36-50): the mean over the steps
+        // of |shortest_angular_distance(yaw, goal yaw)|, as a sum of per-step shares like the
+        // other additive critics of this pass — a tick inside the goal thresholds stays on the
+        // lean kernel instead of falling to the general one (3.7 ms against 0.43 ms for
+        // 2 097 152 x 64 when it did, tools/near_goal_tick.py)
+        const double kw = (double)p.ga_weight / (double)T;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (STEP_OK(r)) lin_d += fabs(normalize_angle((double)(p.ga_goal_yaw - yaw[r]))) * kw;
+        }
+      }
       if (p.flags & SD_GOAL) {
         const double kw = (double)p.goal_weight / (double)T;
 #pragma unroll

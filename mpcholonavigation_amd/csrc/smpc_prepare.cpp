@@ -369,17 +369,18 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   // persistent grid: as many blocks as stay resident, never more than the work
   const uint32_t waves_per_block = (pass_block(c->R) / 64);
   int mode_now = c->score_mode_for(cr);
-  // the lean kernels: MODE 0 scores the north star's five, MODE 3 also the additive forms of Cost,
-  // Goal, Constraint, Twirling and PathAngle (the deployed list); everything else (a cost_power
-  // other than 1, trajectory write-out, path orientations, an active GoalAngle term, a footprint,
-  // VelocityDeadband) takes the general pass
-  const uint32_t lean_extra = SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE;
-  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | SD_GOAL_ANGLE | (SD_EXTRA_CRITICS & ~lean_extra))) {
+  // the lean kernels: MODE 0 scores the north star's five away from the goal, MODE 3 also the
+  // additive forms of Cost, Goal, Constraint, Twirling, PathAngle (the deployed list) and of the
+  // near-goal GoalAngle term; everything else (a cost_power other than 1, trajectory write-out,
+  // path orientations, a footprint, VelocityDeadband) takes the general pass
+  const uint32_t lean_extra = SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE | SD_GOAL_ANGLE;
+  if (gates & (SD_STORE_TRAJ | SD_USE_PATH_YAW | (SD_EXTRA_CRITICS & ~lean_extra))) {
     mode_now = 2;
   } else if (gates & lean_extra) {
     const bool unit_powers = (!cr.constraint.enabled || cr.constraint.cost_power == 1) &&
       (!cr.cost.enabled || cr.cost.cost_power == 1) && (!cr.goal.enabled || cr.goal.cost_power == 1) &&
-      (!cr.twirling.enabled || cr.twirling.cost_power == 1) && (!cr.path_angle.enabled || cr.path_angle.cost_power == 1);
+      (!cr.twirling.enabled || cr.twirling.cost_power == 1) && (!cr.path_angle.enabled || cr.path_angle.cost_power == 1) &&
+      (!(gates & SD_GOAL_ANGLE) || cr.goal_angle.cost_power == 1);
     mode_now = (mode_now == 0 && unit_powers) ? 3 : 2;
   }
   if (c->occ_lds != c->lds.total || c->occ_mode != mode_now) {
