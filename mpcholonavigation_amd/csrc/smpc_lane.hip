@@ -254,7 +254,7 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // from HBM.  Without the 128 parked registers and the per-wave LDS slot a lane needs ~1/2 of
 // the register file's per-wave share: 256-thread blocks, three per CU (three waves per SIMD).
 // The only form for T > 64 (3 T parked values per lane do not fit any register budget).
-template <bool FULL, bool OBST, bool MANY, int NCH, bool RR>
+template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false>
 __global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, (RR && LANE_BLOCK_RR == 256) ? 3 : 1)
 smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ many)
 {
@@ -393,6 +393,10 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   float pa_inv_spacing = 0.f;
   if (pa_on && S > 1 && tk.D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / tk.D[S - 1];
   const bool want_local_furthest = (p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST);
+  // GoalAngleCritic is a near-goal term: it is compiled into instances of their own (GA), which the
+  // launcher picks when the tick's flags carry it — as a run-time branch of the cruise
+  // instances it cost them 1.3-3 % (413 against 401 us on the 2 097 152-rollout pass)
+  constexpr bool ga_on = GA;
   const uint32_t nquad = (T + 3u) >> 2;
 
   // ---- per-wave running softmax state; U[ctrl][t] lives in lane t ----------------
@@ -476,6 +480,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     auto lookup_issue_byte = [&](uint32_t idx) {cell_q = s_map[idx];};
 #endif
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    float ga_sum = 0.f;   // GoalAngleCritic: sum over the steps of |shortest angular distance to the goal's yaw|
     // PathAlign running state (path_align_critic.cpp:92-133)
     // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
     float traj_dist = 0.f, pa_sum = 0.f, pa_num = 0.f, sx_prev = p.x00f, sy_prev = p.y00f;
@@ -509,6 +514,19 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       const float dyr = vx * sn_prev + vy * cs_prev;
       ax = ax + dxr * dt;
       ay = ay + dyr * dt;
+      if (ga_on) {
+        // GoalAngleCritic (goal_angle_critic.cpp:36-50), near-goal ticks only (a uniform branch):
+        // |normalize_angles(goal yaw - yaw)|.  The reference normalises in double; here the
+        // float difference (the reference's own) is reduced by 2 pi in two fused multiply-adds
+        // — the remainder is within 2e-7 of the double one, the mean of 64 of them moves the
+        // rollout's cost by ~1e-7 relative.
+        const float a = p.ga_goal_yaw - yaw;
+        const float kf = fmaf(a, 0.15915494309189535f, 12582912.0f);
+        const float k = kf - 12582912.0f;
+        float r = fmaf(-k, 6.2831854820251465f, a);
+        r = fmaf(-k, -1.7484555e-07f, r);
+        ga_sum += fabsf(r);
+      }
       // The trajectory point itself, x = (float)(x0 + (double)ax) as the reference narrows it
       // (optimizer.cpp:331-342), is formed only where its VALUE is consumed: at PathAlign's
       // sample steps, at the endpoint and on the exact path of the cell index below.  The
@@ -818,6 +836,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
 #else
     if (p.flags & SD_PREFER_FORWARD) lin += pfw * p.pfw_weight;
 #endif
+    if (ga_on) uni += (ga_sum / (float)T) * p.ga_weight;
     lin += p.g_vx * gx;
     lin += p.g_wz * gz;
     lin += p.g_vy * gy;
@@ -984,6 +1003,16 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
     return hipGetLastError();
   }
   const bool full = p.T == 64u;
+  if (p.flags & SD_GOAL_ANGLE) {   // near-goal tick: the instances with the GoalAngle term
+    if (!obst) return hipErrorInvalidValue;
+#define SMPC_LANE_LAUNCH_GA(F) \
+  hipLaunchKernelGGL((smpc_pass_lane<F, true, false, 1, false, true>), dim3(grid), dim3(block), L.total, st, p, L, \
+                     static_cast<const SmpcDev*>(nullptr))
+    if (full) SMPC_LANE_LAUNCH_GA(true);
+    else SMPC_LANE_LAUNCH_GA(false);
+#undef SMPC_LANE_LAUNCH_GA
+    return hipGetLastError();
+  }
 #define SMPC_LANE_LAUNCH(F, O) \
   hipLaunchKernelGGL((smpc_pass_lane<F, O, false, 1, false>), dim3(grid), dim3(block), L.total, st, p, L, \
                      static_cast<const SmpcDev*>(nullptr))
@@ -1016,7 +1045,7 @@ hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool fu
 uint32_t smpc_lane_block() {return LANE_BLOCK;}
 uint32_t smpc_lane_block_rr() {return LANE_BLOCK_RR;}
 
-static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8, 9: re-read with one, two chunks
+static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8, 9: re-read with one, two chunks; 10, 11: GoalAngle
 {
   switch (k & 15) {
     case 0: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, false, 1, false>);
@@ -1028,7 +1057,9 @@ static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8
     case 6: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, true, 1, false>);
     case 7: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, true, 1, false>);
     case 8: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, true>);
-    default: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 2, true>);
+    case 9: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 2, true>);
+    case 10: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, true>);   // near-goal
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, true>);
   }
 }
 
@@ -1047,7 +1078,7 @@ hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_pe
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 10 && e == hipSuccess; ++k)
+  for (int k = 0; k < 12 && e == hipSuccess; ++k)
     e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }

@@ -398,7 +398,11 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
-  c->lane_now = c->use_tpr && mode_now == 0 && T <= kLaneMaxT;
+  // the lane-per-rollout pass scores the north star's five, GoalAngle (power 1) included
+  // (its GoalAngle instances: the parking form with ObstaclesCritic scored, T <= 64)
+  const bool lane_mode = mode_now == 0 ||
+    (mode_now == 3 && !(gates & (lean_extra & ~SD_GOAL_ANGLE)) && (gates & SD_OBSTACLES) && T <= 64);
+  c->lane_now = c->use_tpr && lane_mode && T <= kLaneMaxT;
   // the lane pass samples PathAlign's trajectory points at the first step of every quad:
   // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
   if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
