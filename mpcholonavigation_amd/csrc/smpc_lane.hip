@@ -254,11 +254,16 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // from HBM.  Without the 128 parked registers and the per-wave LDS slot a lane needs ~1/2 of
 // the register file's per-wave share: 256-thread blocks, three per CU (three waves per SIMD).
 // The only form for T > 64 (3 T parked values per lane do not fit any register budget).
-template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false>
+template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false, bool QUADS = FULL>
 __global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, (RR && LANE_BLOCK_RR == 256) ? 3 : 1)
 smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ many)
 {
   static_assert(RR || NCH == 1, "parked controls: one chunk of 64 steps");
+  // QUADS: T is a multiple of four, so every step of every executed quad is live and the time
+  // loop carries no per-step "t < T" branch.  The reference's default horizon is 56: with the
+  // branch around every step the scheduler cannot overlap neighbouring steps, and 56 steps took
+  // LONGER than 64 (67.7 against 59.1 us at 262 144 rollouts).
+  static_assert(!FULL || QUADS, "T == 64 is a multiple of four");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
   // (this pass reads its tick block from device memory only: it fetches u with scalar loads quad
   // by quad, group after group, and reads of the kernarg segment are not cached the way plain
@@ -656,10 +661,12 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     // The control sequence of the next four steps is fetched (scalar loads) a quad ahead too.
     const uint32_t loff = bl * 4u;
     auto ld = [&](uint32_t tensor, uint32_t t) -> float {
+      // (the whole-quads instances of T < 64 prefetch unconditionally — see run_quad — so their
+      // last quad's prefetch is clamped to the last row; T = 64: never out of range)
       const uint32_t tc = (FULL || t < T) ? t : T - 1;
       return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, loff, tensor * noise_bytes + tc * row_bytes, 0));
     };
-    auto ldu = [&](uint32_t ctrl, uint32_t t) -> float {return cu[ctrl * T + (t < T ? t : T - 1)];};
+    auto ldu = [&](uint32_t ctrl, uint32_t t) -> float {return cu[ctrl * T + ((FULL || t < T) ? t : T - 1)];};
     float nq[12], uq[12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -686,7 +693,12 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       float uc[12];
 #pragma unroll
       for (int j = 0; j < 12; ++j) uc[j] = uq[j];
-      if (q + 1 < nquad) {
+      // The next quad's controls and noise are fetched a quad ahead.  Where the trip count is a
+      // run-time value (T < 64) the fetch is unconditional — the last quad re-reads the last
+      // row: behind a run-time "is there a next quad" the waitcnt pass gives up the prefetch
+      // depth (every wait became vmcnt(0), and 56 steps took longer than 64).
+      constexpr bool kAlwaysAhead = QUADS && !FULL;
+      if (kAlwaysAhead || q + 1 < nquad) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -697,13 +709,13 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
         const uint32_t t = 4 * q + i;
         // this step's noise; its registers are refilled at once with step t + 4
         const float n0 = nq[3 * i], n1 = nq[3 * i + 1], n2 = nq[3 * i + 2];
-        if (q + 1 < nquad) {
+        if (kAlwaysAhead || q + 1 < nquad) {
           nq[3 * i + 0] = ld(0, t + 4);
           nq[3 * i + 1] = ld(1, t + 4);
           nq[3 * i + 2] = ld(2, t + 4);
         }
         cq[3 * i] = cq[3 * i + 1] = cq[3 * i + 2] = 0.f;
-        if (FULL || t < T)
+        if (QUADS || t < T)
           do_step(t, i == 0, uc[3 * i], uc[3 * i + 1], uc[3 * i + 2], n0, n1, n2, cq[3 * i], cq[3 * i + 1],
                   cq[3 * i + 2]);
 #if LANE_X_PARK_STEP
@@ -730,31 +742,75 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     } else {
       // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
       const uint32_t qh = nquad < 8u ? nquad : 8u;
-#pragma unroll 2
-      for (uint32_t q = 0; q < qh; ++q) {
-        float cq[12];
-        run_quad(std::false_type{}, q, cq);
+      if constexpr (QUADS && !FULL) {
+        auto quad_lo = [&](const uint32_t q) {
+          float cq[12];
+          run_quad(std::false_type{}, q, cq);
 #if !LANE_X_PARK_STEP
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          PX0[8 * i + q] = cq[3 * i];
-          PY0[8 * i + q] = cq[3 * i + 1];
-          park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
-        }
+          for (int i = 0; i < 4; ++i) {
+            PX0[8 * i + q] = cq[3 * i];
+            PY0[8 * i + q] = cq[3 * i + 1];
+            park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+          }
 #endif
-      }
-#pragma unroll 2
-      for (uint32_t q = 8; q < nquad; ++q) {
-        float cq[12];
-        run_quad(std::true_type{}, q, cq);
+        };
+        auto quad_hi = [&](const uint32_t q) {
+          float cq[12];
+          run_quad(std::true_type{}, q, cq);
 #if !LANE_X_PARK_STEP
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          PX1[8 * i + (q - 8)] = cq[3 * i];
-          PY1[8 * i + (q - 8)] = cq[3 * i + 1];
-          park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
-        }
+          for (int i = 0; i < 4; ++i) {
+            PX1[8 * i + (q - 8)] = cq[3 * i];
+            PY1[8 * i + (q - 8)] = cq[3 * i + 1];
+            park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+          }
 #endif
+        };
+        // two quads per iteration by hand: with a run-time trip count "#pragma unroll 2" is not
+        // honoured here, and one quad per iteration leaves the scheduler nothing to overlap
+        // the next quad's loads and lookups with (699 VALU per 4 steps in a loop of its own)
+        uint32_t q = 0;
+        for (; q + 1 < qh; q += 2) {
+          quad_lo(q);
+          quad_lo(q + 1);
+        }
+        if (q < qh) quad_lo(q);
+        q = 8;
+        for (; q + 1 < nquad; q += 2) {
+          quad_hi(q);
+          quad_hi(q + 1);
+        }
+        if (q < nquad) quad_hi(q);
+      } else {
+        // (the T = 64 instances: these two loops verbatim — moving their bodies into lambdas cost
+        // the main instance 896 bytes of scratch)
+#pragma unroll 2
+        for (uint32_t q = 0; q < qh; ++q) {
+          float cq[12];
+          run_quad(std::false_type{}, q, cq);
+#if !LANE_X_PARK_STEP
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            PX0[8 * i + q] = cq[3 * i];
+            PY0[8 * i + q] = cq[3 * i + 1];
+            park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+          }
+#endif
+        }
+#pragma unroll 2
+        for (uint32_t q = 8; q < nquad; ++q) {
+          float cq[12];
+          run_quad(std::true_type{}, q, cq);
+#if !LANE_X_PARK_STEP
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            PX1[8 * i + (q - 8)] = cq[3 * i];
+            PY1[8 * i + (q - 8)] = cq[3 * i + 1];
+            park[(4 * q + i) * LANE_PARK_STRIDE + lane] = cq[3 * i + 2];
+          }
+#endif
+        }
       }
     }
     if (OBST) {   // drain the lookup pipeline: the entries of the last two steps
@@ -1018,6 +1074,9 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
                      static_cast<const SmpcDev*>(nullptr))
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
+  else if (obst && (p.T & 3u) == 0u)   // whole quads (the reference's default T = 56)
+    hipLaunchKernelGGL((smpc_pass_lane<false, true, false, 1, false, false, true>), dim3(grid), dim3(block), L.total, st, p, L,
+                       static_cast<const SmpcDev*>(nullptr));
   else if (obst) SMPC_LANE_LAUNCH(false, true);
   else SMPC_LANE_LAUNCH(false, false);
 #undef SMPC_LANE_LAUNCH
@@ -1059,7 +1118,8 @@ static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8
     case 8: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, true>);
     case 9: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 2, true>);
     case 10: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, true>);   // near-goal
-    default: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, true>);
+    case 11: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, true>);
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true>);   // whole quads
   }
 }
 
@@ -1078,7 +1138,7 @@ hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_pe
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 12 && e == hipSuccess; ++k)
+  for (int k = 0; k < 13 && e == hipSuccess; ++k)
     e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }
