@@ -697,7 +697,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       // run-time value (T < 64) the fetch is unconditional — the last quad re-reads the last
       // row: behind a run-time "is there a next quad" the waitcnt pass gives up the prefetch
       // depth (every wait became vmcnt(0), and 56 steps took longer than 64).
-      constexpr bool kAlwaysAhead = QUADS && !FULL;
+      constexpr bool kAlwaysAhead = !FULL;
       if (kAlwaysAhead || q + 1 < nquad) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
