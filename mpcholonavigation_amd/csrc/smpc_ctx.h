@@ -177,6 +177,10 @@ struct smpc_ctx {
   uint32_t grid_tpr = 0;
   uint32_t lane_block = 0;      // threads per block of the lane pass this tick
   bool in_group = false;        // member of an smpc_group: full-size blocks always (the group fills the CUs by itself)
+  // developer knobs, read from the environment when the context is created (never per tick)
+  uint32_t knob_max_blocks_per_cu = 0;   // SMPC_MAX_BLOCKS_PER_CU
+  bool knob_lane_reread = false;         // SMPC_LANE_REREAD=1: the re-read form for T = 64 too
+  bool knob_no_inline_tick = false;      // SMPC_NO_INLINE_TICK
   bool half_blocks = true;      // (SMPC_NO_HALF_BLOCKS, read when the context is created: experiments)
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;
   float* d_costs[2] = {nullptr, nullptr};

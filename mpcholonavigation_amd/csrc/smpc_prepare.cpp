@@ -340,14 +340,16 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     // the reach at the largest constrained speed plus four standard deviations of the mean
     // noise, up to kWindowSideMax cells; the passes that run T > 64 (the re-read form, the
     // wave-per-rollout pass) have the LDS for it.
-    if (T > 64 && !getenv("SMPC_SMALL_WINDOW")) {
+    static const bool small_window = getenv("SMPC_SMALL_WINDOW") != nullptr;              // (experiments; read once)
+    static const char* const side_max_env = getenv("SMPC_WINDOW_SIDE_MAX");
+    if (T > 64 && !small_window) {
       const float sigma = std::max(c->cfg.vx_std, c->holonomic ? c->cfg.vy_std : 0.f);
       const float vmax = std::max(std::max(std::fabs(c->c_vx_max), std::fabs(c->c_vx_min)), std::fabs(c->c_vy)) +
         4.f * sigma / std::sqrt(static_cast<float>(T));
       const double reach_cells = static_cast<double>(T) * c->cfg.model_dt * vmax / c->map.res;
       const uint32_t want = (static_cast<uint32_t>(2.0 * reach_cells) + 8u + 3u) & ~3u;
       uint32_t side_max = kWindowSideMax;
-      if (const char* e = getenv("SMPC_WINDOW_SIDE_MAX")) side_max = static_cast<uint32_t>(atoi(e)) & ~3u;   // experiments
+      if (side_max_env) side_max = static_cast<uint32_t>(atoi(side_max_env)) & ~3u;
       side = std::max(side, std::min(want, side_max));
     }
     const uint32_t ww = std::min(c->map.W, side), wh = std::min(c->map.H, side);
@@ -391,10 +393,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     c->occ_mode = mode_now;
   }
   uint32_t per_cu = std::min(c->occ_blocks, 32u / waves_per_block);
-  if (const char* e = getenv("SMPC_MAX_BLOCKS_PER_CU")) {   // tuning knob
-    const uint32_t lim = static_cast<uint32_t>(atoi(e));
-    if (lim >= 1) per_cu = std::min(per_cu, lim);
-  }
+  if (c->knob_max_blocks_per_cu >= 1) per_cu = std::min(per_cu, c->knob_max_blocks_per_cu);   // SMPC_MAX_BLOCKS_PER_CU
   uint32_t grid = std::min((B + waves_per_block - 1) / waves_per_block,
                            static_cast<uint32_t>(c->num_cu) * per_cu);
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
@@ -408,8 +407,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   if ((gates & SD_PATH_ALIGN) && step != 4) c->lane_now = false;
   // the re-read form (no parked controls): the only one for T > 64; instances exist with
   // ObstaclesCritic scored.  SMPC_LANE_REREAD=1 selects it for T <= 64 too (experiments).
-  const char* e_rr = getenv("SMPC_LANE_REREAD");
-  const bool force_rr = e_rr != nullptr && atoi(e_rr) != 0;
+  const bool force_rr = c->knob_lane_reread;
   c->lane_rr = (T > 64 || force_rr) && (gates & SD_OBSTACLES) != 0 && (T == 64 || T == 128);
   if (T > 64 && !c->lane_rr) c->lane_now = false;
   if (c->lane_now) {
@@ -659,7 +657,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // their own; the CostCritic table (general pass only) is not part of that
   // (contexts of the wave-per-rollout pass only: see smpc_lane.hip for why not the other)
   const bool inline_tick = !c->defer_upload && !c->use_tpr && T <= 64 && tl.lut_cost - tl.px <= SMPC_INLINE_TICK_CAP &&
-    !getenv("SMPC_NO_INLINE_TICK");
+    !c->knob_no_inline_tick;
   if (!c->defer_upload) {
     if (!inline_tick)
       HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
