@@ -393,8 +393,10 @@ def _exchange_agrees(g, scn, rank, HipShard, ShardedOptimizer, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: the first ~60 ticks of a fresh process run inside the device's power-management
+    # transient (tools/ramp.py); 100 + 200 ticks are 0.13 s
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default): --total-rollouts in all, split over the GPUs; "
                          "weak: --rollouts-per-gpu on every GPU")

@@ -18,7 +18,7 @@ for mode in ("closed loop (u shifted every tick)", "the same u every tick", "the
             torch.cuda.synchronize()
     ts, ks = [], []
     g.set_profile(True)        # (HIP events around the scoring pass: its own duration per tick)
-    for k in range(160):
+    for k in range(400):
         t0 = time.perf_counter()
         un, out = g.optimize(scn.tick, u)
         if mode.startswith("closed"):
@@ -27,7 +27,7 @@ for mode in ("closed loop (u shifted every tick)", "the same u every tick", "the
         ks.append(out.score_pass_ms * 1e3)
     print(mode)
     print("  tick, first 10:", " ".join(f"{t:.0f}" for t in ts[:10]))
-    print("  tick, then per 10:", " ".join(f"{sum(ts[a:a+10])/10:.0f}" for a in range(10, 160, 10)))
+    print("  tick, then per 10:", " ".join(f"{sum(ts[a:a+10])/10:.0f}" for a in range(10, 400, 10)))
     print("  scoring pass, first 10:", " ".join(f"{t:.0f}" for t in ks[:10]))
-    print("  scoring pass, then per 10:", " ".join(f"{sum(ks[a:a+10])/10:.0f}" for a in range(10, 160, 10)))
+    print("  scoring pass, then per 10:", " ".join(f"{sum(ks[a:a+10])/10:.0f}" for a in range(10, 400, 10)))
     g.close()
