@@ -835,9 +835,9 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     out->pass_kind = c->last_pass_kind;
   }
   if (timing) {
-    static double acc[5] = {0, 0, 0, 0, 0};
-    static unsigned n = 0;
-    static clk::time_point t_prev_out;
+    static thread_local double acc[5] = {0, 0, 0, 0, 0};   // (per calling thread: contexts may tick on several)
+    static thread_local unsigned n = 0;
+    static thread_local clk::time_point t_prev_out;
     const auto t_out = clk::now();
     auto us = [](clk::time_point a, clk::time_point b) {return std::chrono::duration<double, std::micro>(b - a).count();};
     if (n > 0) acc[0] += us(t_prev_out, t_in);   // the caller, between two ticks
