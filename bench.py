@@ -104,6 +104,25 @@ def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0,
     return g, scn, cfg
 
 
+def raise_clocks(g, ms, seed=1234):
+    """Bring the device's clocks up before the warm-up ticks: `ms` milliseconds of the device RNG's
+    redraw kernel (compute-bound, the product's own), then the seed again — the stored noise is
+    bit for bit what it was.  From idle the shader clock takes ~150 ms of load to climb from 2.0
+    to 2.34 GHz (rocm-smi samples: tools/clock_watch.py), so the first ~60 ticks of a fresh
+    process run 10-20 % slower than the rest (tools/ramp.py, tools/warm_test.py: ticks 5-24 take
+    481 us cold, 419 us behind this; steady state ~410).  The metric is steady-state throughput:
+    a run of 5 + 20 ticks should measure what a run of 100 + 200 measures.  W and K are untouched."""
+    if ms <= 0:
+        return
+    import torch
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        g.redraw_noise()
+        torch.cuda.synchronize()
+    g.seed(seed)
+    torch.cuda.synchronize()
+
+
 def run_ticks(step_fn, scn, steps, warmup, sync, barrier, before_tick=None):
     """W untimed ticks, then exactly K timed ones between barrier + synchronize on both sides.
     before_tick (e.g. smpc_redraw_noise) runs inside the timed region when given."""
@@ -404,6 +423,10 @@ def main():
     ap.add_argument("--rollouts-per-gpu", type=int, default=SHARD_ROLLOUTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--clock-warmup-ms", type=float, default=200.0,
+                    help="milliseconds of device-RNG redraws in front of the warm-up ticks, so that the shader "
+                         "clock has climbed (2.0 -> 2.34 GHz over ~150 ms of load) before anything is timed; "
+                         "0: off.  Reported in the JSON line")
     ap.add_argument("--no-speculate", action="store_true",
                     help="N > 1: always exchange the furthest point first (two collectives per tick) "
                          "instead of speculating on the previous tick's value and re-scoring on a miss")
@@ -504,6 +527,7 @@ def main():
             pass
 
     # the timed region: exactly K ticks, no event records in the stream
+    raise_clocks(g, args.clock_warmup_ms)
     el, _, _, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
                                       torch.cuda.synchronize, barrier)
     # kernel duration for the roofline: the same K ticks again with HIP events around every
@@ -606,6 +630,13 @@ def main():
                 "device_ms_per_tick": dev_ms,
                 "timing": f"HIP events around each scoring-pass launch over {args.steps} further ticks "
                           f"({1e3 * el_prof / args.steps:.4f} ms/tick with the event records in the stream)",
+            },
+            "clock_warmup": {
+                "ms": args.clock_warmup_ms,
+                "what": "device-RNG redraw kernels in front of the W warm-up ticks, then the seed again (the stored "
+                        "noise is unchanged); --clock-warmup-ms 0 turns it off.  From idle the shader clock climbs "
+                        "from 2.0 to 2.34 GHz over ~150 ms of load (tools/clock_watch.py): without this, ticks 5-24 of a "
+                        "fresh process take 481 us, behind it 419 us, in steady state ~410 us (tools/warm_test.py)",
             },
             "moving_pose": {
                 "ms_per_step": 1e3 * el_mv / args.steps,
