@@ -104,6 +104,9 @@ def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0,
     return g, scn, cfg
 
 
+CLOCK_WARMUP_MS = 200.0     # --clock-warmup-ms: every timed context gets the same treatment
+
+
 def raise_clocks(g, ms, seed=1234):
     """Bring the device's clocks up before the warm-up ticks: `ms` milliseconds of the device RNG's
     redraw kernel (compute-bound, the product's own), then the seed again — the stored noise is
@@ -217,6 +220,7 @@ def run_moving(step_fn, scn, dt, steps, warmup, sync, barrier):
 def time_config(B, T, map_size, steps, warmup, flags=0, redraw=False, critics=None):
     import torch
     g, scn, cfg = make_ctx(B, T, map_size, flags=flags, critics=critics)
+    raise_clocks(g, CLOCK_WARMUP_MS)
     before = g.redraw_noise if redraw else None
     el, _, _, passes, out = run_ticks(g.optimize, scn, steps, warmup,
                                       torch.cuda.synchronize, lambda: None, before_tick=before)
@@ -250,6 +254,7 @@ def time_multi_query(n_ctx, B, T, map_size, steps, warmup):
     from mpcholonavigation_amd.optimizer import SmpcGroup
     ctxs = [make_ctx(B, T, map_size, seed=1234 + i, flags=A.SMPC_FLAG_LANE_PER_ROLLOUT)
             for i in range(n_ctx)]
+    raise_clocks(ctxs[0][0], CLOCK_WARMUP_MS, seed=1234)
     grp = SmpcGroup([g for g, _, _ in ctxs])
     ticks = [scn.tick for _, scn, _ in ctxs]
     us = [scn.u0 for _, scn, _ in ctxs]
@@ -431,6 +436,8 @@ def main():
                     help="N > 1: always exchange the furthest point first (two collectives per tick) "
                          "instead of speculating on the previous tick's value and re-scoring on a miss")
     args = ap.parse_args()
+    global CLOCK_WARMUP_MS
+    CLOCK_WARMUP_MS = args.clock_warmup_ms
 
     import torch
     import torch.distributed as dist
