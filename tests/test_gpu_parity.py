@@ -346,7 +346,9 @@ def test_lane_transpose_reduce(Smpc):
 
 @pytest.mark.parametrize("B,T,M", [(1000, 30, 200), (4096, 64, 200), (8192, 64, 2000), (2500, 56, 200),
                                    (2500, 100, 200), (300, 61, 200), (65, 3, 200), (64, 1, 200),
-                                   (4096, 128, 2000), (3000, 128, 200), (130, 128, 200)])
+                                   (4096, 128, 2000), (3000, 128, 200), (130, 128, 200),
+                                   # horizons that are multiples of four below 64: the whole-quads instance
+                                   (777, 4, 200), (1500, 36, 200), (3000, 60, 200), (70000, 56, 200)])
 def test_lane_per_rollout_pass_parity(Smpc, Oracle, B, T, M):
     """The lane-per-rollout pass (csrc/smpc_lane.hip: lane = rollout, sequential in time,
     in-register transpose-reduce) against the oracle.  Ticks take it for T <= 64 with the
