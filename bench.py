@@ -21,7 +21,8 @@ and regenerate_noises = true.
 
 At N > 1 the exchange is RCCL called from inside libsmpc (smpc_shard_tick: one
 ncclAllGather of the shard tuples per tick on the ctx's stream).  The
-collective-free mailbox exchange (smpc_shard_p2p_*) is timed next to it and
+collective-free mailbox exchange (smpc_shard_p2p_*) is timed next to it (by
+default in the two-rank run only; SMPC_BENCH_ALTERNATIVES=1: at every N) and
 reported under "exchange_alternatives"; SMPC_BENCH_EXCHANGE=mailbox|torch
 makes another implementation the headline.  Every fall-through is recorded in
 the JSON line (config.exchange_fallbacks), not only on stderr.
@@ -553,8 +554,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, pass_ms, el_mv = float(t[0]), float(t[1]), float(t[2])
 
-    # N > 1: the exchange implementations that are not the headline, timed on the same workload
-    if world > 1 and os.environ.get("SMPC_BENCH_ALTERNATIVES", "1") != "0":
+    # N > 1: the exchange implementations that are not the headline, timed on the same workload.
+    # By default only in the two-rank run: the mailbox exchange has never crossed xGMI (one-GPU
+    # rehearsals only), and if it were to fault there it would take this process — and the line
+    # of this N — with it; the N = 4 and N = 8 lines do not depend on it.  SMPC_BENCH_ALTERNATIVES=1
+    # forces them at every N, =0 never.
+    alt_env = os.environ.get("SMPC_BENCH_ALTERNATIVES", "")
+    if world > 1 and (alt_env == "1" or (alt_env == "" and world == 2)):
         for kind in ("rccl", "mailbox", "torch"):
             if kind == headline_kind:
                 continue
