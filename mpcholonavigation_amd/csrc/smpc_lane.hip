@@ -254,7 +254,7 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // from HBM.  Without the 128 parked registers and the per-wave LDS slot a lane needs ~1/2 of
 // the register file's per-wave share: 256-thread blocks, three per CU (three waves per SIMD).
 // The only form for T > 64 (3 T parked values per lane do not fit any register budget).
-template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false, bool QUADS = FULL>
+template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false, bool QUADS = FULL, int TC = 0>
 __global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, (RR && LANE_BLOCK_RR == 256) ? 3 : 1)
 smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ many)
 {
@@ -264,6 +264,9 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // branch around every step the scheduler cannot overlap neighbouring steps, and 56 steps took
   // LONGER than 64 (67.7 against 59.1 us at 262 144 rollouts).
   static_assert(!FULL || QUADS, "T == 64 is a multiple of four");
+  // TC: a horizon below 64 known at compile time (the reference's default, 56): trip counts,
+  // bound checks and the control sequence's offsets fold as they do for T == 64
+  static_assert(TC == 0 || (!FULL && QUADS && !RR && TC < 64 && (TC & 3) == 0), "compile-time horizon: whole quads below 64");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
   // (this pass reads its tick block from device memory only: it fetches u with scalar loads quad
   // by quad, group after group, and reads of the kernarg segment are not cached the way plain
@@ -365,13 +368,13 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // u and the path are inputs of the launch: read them through the constant address space,
   // so that uniform loads stay scalar loads although the kernel also stores to global memory
   const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
-  const uint32_t T = FULL ? 64u * NCH : p.T, B = p.B;
+  const uint32_t T = FULL ? 64u * NCH : (TC ? (uint32_t)TC : p.T), B = p.B;
   // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
   // three tensors, the lane's own offset (b * 4) is the vector offset
   // (the host lays the three [T,B] tensors out back to back: ONE descriptor, four scalar
   // registers instead of twelve — the loop is short of them — and the tensor is part of the
   // scalar offset)
-  const uint32_t noise_bytes = p.T * B * 4u;
+  const uint32_t noise_bytes = T * B * 4u;
   const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvx), 0, 3u * noise_bytes, 0x00020000);
   const uint32_t row_bytes = B * 4u;
   const float dt = p.dt, yaw0 = p.yaw0;
@@ -697,7 +700,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       // run-time value (T < 64) the fetch is unconditional — the last quad re-reads the last
       // row: behind a run-time "is there a next quad" the waitcnt pass gives up the prefetch
       // depth (every wait became vmcnt(0), and 56 steps took longer than 64).
-      constexpr bool kAlwaysAhead = !FULL;
+      constexpr bool kAlwaysAhead = !FULL && TC == 0;
       if (kAlwaysAhead || q + 1 < nquad) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -742,7 +745,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     } else {
       // steps [0, 32) park into the <..>0 tuples, [32, 64) into <..>1, element t % 32
       const uint32_t qh = nquad < 8u ? nquad : 8u;
-      if constexpr (QUADS && !FULL) {
+      if constexpr (QUADS && !FULL && TC == 0) {
         auto quad_lo = [&](const uint32_t q) {
           float cq[12];
           run_quad(std::false_type{}, q, cq);
@@ -1074,7 +1077,10 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
                      static_cast<const SmpcDev*>(nullptr))
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
-  else if (obst && (p.T & 3u) == 0u)   // whole quads (the reference's default T = 56)
+  else if (obst && p.T == 56u)         // the reference's default horizon, at compile time
+    hipLaunchKernelGGL((smpc_pass_lane<false, true, false, 1, false, false, true, 56>), dim3(grid), dim3(block), L.total, st, p, L,
+                       static_cast<const SmpcDev*>(nullptr));
+  else if (obst && (p.T & 3u) == 0u)   // whole quads
     hipLaunchKernelGGL((smpc_pass_lane<false, true, false, 1, false, false, true>), dim3(grid), dim3(block), L.total, st, p, L,
                        static_cast<const SmpcDev*>(nullptr));
   else if (obst) SMPC_LANE_LAUNCH(false, true);
@@ -1119,7 +1125,8 @@ static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8
     case 9: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 2, true>);
     case 10: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, true>);   // near-goal
     case 11: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, true>);
-    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true>);   // whole quads
+    case 12: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true>);   // whole quads
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56>);   // T = 56
   }
 }
 
@@ -1138,7 +1145,7 @@ hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_pe
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 13 && e == hipSuccess; ++k)
+  for (int k = 0; k < 14 && e == hipSuccess; ++k)
     e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }
