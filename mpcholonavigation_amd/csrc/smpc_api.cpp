@@ -483,6 +483,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   if (const char* e = getenv("SMPC_MAX_BLOCKS_PER_CU")) c->knob_max_blocks_per_cu = static_cast<uint32_t>(std::max(0, atoi(e)));
   if (const char* e = getenv("SMPC_LANE_REREAD")) c->knob_lane_reread = atoi(e) != 0;
   c->knob_no_inline_tick = getenv("SMPC_NO_INLINE_TICK") != nullptr;
+  c->knob_pinned_tick = getenv("SMPC_PINNED_TICK") != nullptr;
   c->fused_reduce = getenv("SMPC_FUSED_REDUCE") != nullptr;   // (read per context: tests compare the two)
   CK(hipMalloc(&c->d_furthest, 32));
   CK(hipMemset(c->d_furthest, 0, 32));

@@ -658,7 +658,12 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // (contexts of the wave-per-rollout pass only: see smpc_lane.hip for why not the other)
   const bool inline_tick = !c->defer_upload && !c->use_tpr && T <= 64 && tl.lut_cost - tl.px <= SMPC_INLINE_TICK_CAP &&
     !c->knob_no_inline_tick;
-  if (!c->defer_upload) {
+  // SMPC_PINNED_TICK=1 (experiment): no copy at all — the kernels read the tick block where the
+  // host assembled it, in pinned host memory.  Measured (tools/tail_ab.py SMPC_PINNED_TICK=1) and
+  // not the default: every block of the grid fetches its ~2 KB across PCIe, uncached.
+  const bool pinned_tick = c->knob_pinned_tick && !c->defer_upload && !inline_tick;
+  const uint8_t* const tb = pinned_tick ? h : c->d_tick;
+  if (!c->defer_upload && !pinned_tick) {
     if (!inline_tick)
       HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
     else if (gates & SD_COST)
@@ -675,7 +680,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.svx = svx; d.svy = svy; d.swz = swz; d.dt = dt;
   d.nvx = c->d_nvx; d.nvy = c->d_nvy; d.nwz = c->d_nwz;
   d.tvx = c->d_tvx; d.tvy = c->d_tvy; d.twz = c->d_twz;
-  d.u = reinterpret_cast<const float*>(c->d_tick + tl.u);
+  d.u = reinterpret_cast<const float*>(tb + tl.u);
   d.traj_x = c->d_traj[0]; d.traj_y = c->d_traj[1]; d.traj_yaw = c->d_traj[2];
   d.map = c->d_map; d.W = c->map.W; d.H = c->map.H;
   d.ox = c->map.ox; d.oy = c->map.oy; d.res = c->map.res;
@@ -694,13 +699,13 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     d.cell_eps = static_cast<float>(std::min(eps, 0.5));
   }
   d.lut = c->d_lut;
-  d.px = reinterpret_cast<const float*>(c->d_tick + tl.px);
-  d.py = reinterpret_cast<const float*>(c->d_tick + tl.py);
-  d.pyaw = reinterpret_cast<const float*>(c->d_tick + tl.pyaw);
-  d.D = reinterpret_cast<const float*>(c->d_tick + tl.D);
-  d.pvalid = c->d_tick + tl.pvalid;
-  d.pa_active = c->d_tick + tl.pa_active;
-  d.pf_idx = reinterpret_cast<const uint32_t*>(c->d_tick + tl.pf_idx);
+  d.px = reinterpret_cast<const float*>(tb + tl.px);
+  d.py = reinterpret_cast<const float*>(tb + tl.py);
+  d.pyaw = reinterpret_cast<const float*>(tb + tl.pyaw);
+  d.D = reinterpret_cast<const float*>(tb + tl.D);
+  d.pvalid = tb + tl.pvalid;
+  d.pa_active = tb + tl.pa_active;
+  d.pf_idx = reinterpret_cast<const uint32_t*>(tb + tl.pf_idx);
   d.obs_critical_w = cr.obstacles.critical_weight;
   d.obs_repulsion_w = cr.obstacles.repulsion_weight;
   d.obs_collision_cost = cr.obstacles.collision_cost;
@@ -719,7 +724,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     d.con_min_vel = min_sgn * sqrtf(cr.constraint.vx_min * cr.constraint.vx_min + cr.constraint.vy_max * cr.constraint.vy_max);
     d.con_acker_r = c->acker_r;
   }
-  d.lut_cost = reinterpret_cast<const float*>(c->d_tick + tl.lut_cost);
+  d.lut_cost = reinterpret_cast<const float*>(tb + tl.lut_cost);
   d.cost_w254 = cr.cost.cost_weight / 254.0f;   // cost_critic.cpp:34
   d.cost_collision_cost = cr.cost.collision_cost; d.cost_power = cr.cost.cost_power;
   d.cost_critical = cr.cost.critical_cost;
@@ -727,7 +732,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.goal_x = in->goal_x; d.goal_y = in->goal_y;
   d.goal_weight = cr.goal.cost_weight; d.goal_power = cr.goal.cost_power;
   d.tw_weight = cr.twirling.cost_weight; d.tw_power = cr.twirling.cost_power;
-  d.pang_active = c->d_tick + tl.pang_active;
+  d.pang_active = tb + tl.pang_active;
   d.pang_weight = cr.path_angle.cost_weight; d.pang_power = cr.path_angle.cost_power;
   d.pang_offset = cr.path_angle.offset_from_furthest; d.pang_correct = pang_correct ? 1 : 0;
   d.db_vx = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[0]));
