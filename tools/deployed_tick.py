@@ -14,7 +14,8 @@ DEPLOYED = ("constraint", "cost", "goal", "goal_angle", "path_align", "path_foll
 FIVE = ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward")
 ALL = ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward", "cost", "goal", "constraint",
        "twirling", "path_angle", "velocity_deadband")
-for B, T in ((2000, 56), (65536, 56)):
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(2000, 56), (65536, 56)]
+for B, T in SIZES:
     for label, names in (("five", FIVE), ("deployed nine", DEPLOYED)):
         cr = default_critics()
         for n in ALL:
