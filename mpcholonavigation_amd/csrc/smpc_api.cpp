@@ -484,6 +484,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   if (const char* e = getenv("SMPC_LANE_REREAD")) c->knob_lane_reread = atoi(e) != 0;
   c->knob_no_inline_tick = getenv("SMPC_NO_INLINE_TICK") != nullptr;
   c->knob_pinned_tick = getenv("SMPC_PINNED_TICK") != nullptr;
+  c->knob_balanced_grid = getenv("SMPC_NO_BALANCED_GRID") == nullptr;
   c->fused_reduce = getenv("SMPC_FUSED_REDUCE") != nullptr;   // (read per context: tests compare the two)
   CK(hipMalloc(&c->d_furthest, 32));
   CK(hipMemset(c->d_furthest, 0, 32));

@@ -181,6 +181,7 @@ struct smpc_ctx {
   uint32_t knob_max_blocks_per_cu = 0;   // SMPC_MAX_BLOCKS_PER_CU
   bool knob_lane_reread = false;         // SMPC_LANE_REREAD=1: the re-read form for T = 64 too
   bool knob_no_inline_tick = false;      // SMPC_NO_INLINE_TICK
+  bool knob_balanced_grid = true;        // SMPC_NO_BALANCED_GRID=1 turns it off: re-read form, launch only the waves that fill every round
   bool knob_pinned_tick = false;         // SMPC_PINNED_TICK=1: kernels read the tick block from pinned host memory
   bool half_blocks = true;      // (SMPC_NO_HALF_BLOCKS, read when the context is created: experiments)
   uint32_t occ_tpr_blocks = 0, occ_tpr_lds = 0xffffffffu;

@@ -39,7 +39,12 @@
 #endif
 #define LANE_BLOCK 512   // 8 waves: 2 per SIMD, 256 registers each
 #ifndef LANE_BLOCK_RR
-#define LANE_BLOCK_RR 256   // the re-read instances: 4 waves, three blocks per CU
+// the re-read instances: 8 waves, one block per CU like the parking form.  (First built with 4
+// waves and three blocks per CU: 136 registers allow three waves per SIMD.  The pass is
+// VALU-bound either way, three blocks stage three copies of the window, and 4096 groups on 3072
+// waves leave a ragged second round: 262 144 x 128 the same within noise, 131 072 x 128: 86 -> 78 us,
+// 70 000 x 128: 73 -> 67 us.)
+#define LANE_BLOCK_RR 512
 #endif
 
 // experiment switches (tools/variants.sh builds the library with some of them off)

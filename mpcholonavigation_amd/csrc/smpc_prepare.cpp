@@ -415,7 +415,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     c->lane_window_bytes = window_bytes;
     c->lds_tpr = Lt;
     if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
-    // (the re-read form runs three blocks per CU on more than SMPC_TAIL_MAX_GRID blocks)
+    // (the re-read form: no in-launch reduction, smpc_lane.hip)
     if (!c->lane_rr) c->lds_tpr.total = std::max(Lt.total, smpc_tail_lds_bytes(T));
   }
   if (c->lane_now) {
@@ -426,7 +426,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
       int nb = 0;
       const hipError_t e = c->lane_rr ? smpc_lane_occupancy_rr(T, Lt.total, &nb) : smpc_lane_occupancy(T == 64, Lt.total, &nb);
       if (e != hipSuccess || nb < 1) nb = 1;
-      if (c->lane_rr && nb > 3) nb = 3;   // launch bounds: three waves per SIMD
+      if (c->lane_rr && nb > 3) nb = 3;   // (four-wave blocks: launch bounds of three waves per SIMD)
       c->occ_tpr_blocks = static_cast<uint32_t>(nb);
       c->occ_tpr_lds = occ_key;
     }
@@ -443,6 +443,24 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     }
     uint32_t g = std::min((groups + wpb - 1) / wpb, static_cast<uint32_t>(c->num_cu) * c->occ_tpr_blocks);
     g = std::max(1u, std::min(g, kMaxGrid));
+    // Every wave takes whole groups, so a launch lasts ceil(groups / waves) group-times whatever
+    // the remainder: launch only the waves that fill every round, and — where several blocks fit
+    // a CU — pad the launch's LDS so that the dispatcher cannot stack them unevenly.  (Built for
+    // the re-read form's first shape, four-wave blocks at three per CU: 4096 groups on 3072 waves;
+    // with the eight-wave blocks it has now the grid is one block per CU and this trims nothing
+    // at the benchmarked sizes.  SMPC_NO_BALANCED_GRID=1: off.)
+    if (c->lane_rr && c->knob_balanced_grid) {
+      const uint32_t waves = g * wpb;
+      const uint32_t rounds = (groups + waves - 1) / waves;
+      const uint32_t need = (groups + rounds - 1) / rounds;
+      const uint32_t g2 = (need + wpb - 1) / wpb;
+      const uint32_t per_cu = (g2 + c->num_cu - 1) / static_cast<uint32_t>(c->num_cu);
+      if (g2 < g && per_cu < c->occ_tpr_blocks) {
+        g = g2;
+        const uint32_t pad = align_up(kLdsPerCu / (per_cu + 1) + 1024u, 16);
+        if (pad <= kLdsPerCu / per_cu) c->lds_tpr.total = std::max(c->lds_tpr.total, pad);
+      }
+    }
     c->grid_tpr = g;
     // window-relative float cell index and its guard band.  The pass forms
     //   q~ = fma(ax, (1/res)_f, cxf),   cxf = ((x0 - window corner) / res)_f
