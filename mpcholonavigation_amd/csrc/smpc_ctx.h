@@ -176,6 +176,7 @@ struct smpc_ctx {
   SmpcLds lds_tpr{};
   uint32_t grid_tpr = 0;
   uint32_t lane_block = 0;      // threads per block of the lane pass this tick
+  bool pang_any = false;        // this tick: PathAngleCritic is live for some candidate furthest point (prepare_tick)
   bool in_group = false;        // member of an smpc_group: full-size blocks always (the group fills the CUs by itself)
   // developer knobs, read from the environment when the context is created (never per tick)
   uint32_t knob_max_blocks_per_cu = 0;   // SMPC_MAX_BLOCKS_PER_CU

@@ -122,8 +122,10 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     flags[i] = scoring_flags(c, c->fail_in);
     const bool need_f = (flags[i] & SD_NEED_FURTHEST) != 0;
     if (need_f) flags[i] |= SD_LOCAL_FURTHEST;
-    // (a near-goal member scores GoalAngle: instances of the lane pass the batched launch does not have)
-    const bool ok = c->lane_now && !c->lane_rr && !(flags[i] & SD_GOAL_ANGLE) && c->cfg.iteration_count == 1 && !c->fail_in &&
+    // (a near-goal member scores GoalAngle, a member with the deployed critic list Constraint / Cost /
+    // Twirling: instances of the lane pass the batched launch does not have)
+    const bool ok = c->lane_now && !c->lane_rr && !(flags[i] & (SD_GOAL_ANGLE | SD_CONSTRAINT | SD_COST | SD_TWIRLING)) &&
+      c->cfg.iteration_count == 1 && !c->fail_in &&
       !(c->cfg.flags & (SMPC_FLAG_NO_SPECULATION | SMPC_FLAG_PROFILE)) && (!need_f || c->hint_valid) &&
       c->poll_enabled && c->acker_r < 0.f;
     if (!ok) batched = false;

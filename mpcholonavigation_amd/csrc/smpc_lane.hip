@@ -259,7 +259,7 @@ __device__ __forceinline__ uint32_t cell_byte_exact(const SmpcDev& p, uint8_t* s
 // from HBM.  Without the 128 parked registers and the per-wave LDS slot a lane needs ~1/2 of
 // the register file's per-wave share: 256-thread blocks, three per CU (three waves per SIMD).
 // The only form for T > 64 (3 T parked values per lane do not fit any register budget).
-template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false, bool QUADS = FULL, int TC = 0>
+template <bool FULL, bool OBST, bool MANY, int NCH, bool RR, bool GA = false, bool QUADS = FULL, int TC = 0, bool DEP = false>
 __global__ void __launch_bounds__(RR ? LANE_BLOCK_RR : LANE_BLOCK, (RR && LANE_BLOCK_RR == 256) ? 3 : 1)
 smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ many)
 {
@@ -272,6 +272,14 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // TC: a horizon below 64 known at compile time (the reference's default, 56): trip counts,
   // bound checks and the control sequence's offsets fold as they do for T == 64
   static_assert(TC == 0 || (!FULL && QUADS && !RR && TC < 64 && (TC & 3) == 0), "compile-time horizon: whole quads below 64");
+  // DEP: the cruise tick of the reference's deployed critic list (robot_bringup/config/
+  // nav2_params.yaml:222: Constraint, Cost, Goal, GoalAngle, PathAlign, PathFollow, PathAngle,
+  // PreferForward, Twirling).  Away from the goal and on the path, Goal, GoalAngle and PathAngle
+  // are gated off (the host checks), Cost takes ObstaclesCritic's place in the lookup pipeline —
+  // same costAtPose, same collision rule, its per-cost term in the table's second field — and
+  // Constraint and Twirling are two more additive per-step terms (power 1, in float like the
+  // other sums of this pass).  Instances of their own: the cruise instances of the five pay nothing.
+  static_assert(!DEP || (OBST && !RR && !MANY && !GA), "deployed-list instances: parking form, single instance");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
   // (this pass reads its tick block from device memory only: it fetches u with scalar loads quad
   // by quad, group after group, and reads of the kernarg segment are not cached the way plain
@@ -406,6 +414,10 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   float pa_inv_spacing = 0.f;
   if (pa_on && S > 1 && tk.D[S - 1] > 0.f) pa_inv_spacing = (float)(S - 1) / tk.D[S - 1];
   const bool want_local_furthest = (p.flags & SD_NEED_FURTHEST) && (p.flags & SD_LOCAL_FURTHEST);
+  const bool con_on = DEP && (p.flags & SD_CONSTRAINT) != 0, tw_on = DEP && (p.flags & SD_TWIRLING) != 0;
+  const float k_con = p.dt * p.con_weight, k_tw = p.tw_weight / (float)(FULL ? 64 * NCH : (TC ? TC : (int)p.T));
+  // CostCritic in ObstaclesCritic's place (DEP): the table's second field holds its per-cost term
+  const bool cost_mode = DEP && (p.flags & SD_COST) != 0;
   // GoalAngleCritic is a near-goal term: it is compiled into instances of their own (GA), which the
   // launcher picks when the tick's flags carry it — as a run-time branch of the cruise
   // instances it cost them 1.3-3 % (413 against 401 us on the 2 097 152-rollout pass)
@@ -494,6 +506,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
 #endif
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     float ga_sum = 0.f;   // GoalAngleCritic: sum over the steps of |shortest angular distance to the goal's yaw|
+    float ext = 0.f;      // DEP: ConstraintCritic + TwirlingCritic, weights and 1/T folded in
     // PathAlign running state (path_align_critic.cpp:92-133)
     // (trajectory point 0 is the same for every rollout: host-computed, same arithmetic)
     float traj_dist = 0.f, pa_sum = 0.f, pa_num = 0.f, sx_prev = p.x00f, sy_prev = p.y00f;
@@ -527,6 +540,19 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       const float dyr = vx * sn_prev + vy * cs_prev;
       ax = ax + dxr * dt;
       ay = ay + dyr * dt;
+      if constexpr (DEP) {
+        // ConstraintCritic (constraint_critic.cpp:41-75; holonomic and differential models: the
+        // host keeps Ackermann off these instances): how far the signed speed leaves
+        // [min_vel, max_vel], times dt and the weight
+        if (con_on) {
+          const float sp = fast_sqrt(vx * vx + vy * vy);
+          const float vt = vx > 0.f ? sp : -sp;
+          const float e = fmaxf(vt - p.con_max_vel, 0.f) + fmaxf(p.con_min_vel - vt, 0.f);
+          ext = fmaf(e, k_con, ext);
+        }
+        // TwirlingCritic (twirling_critic.cpp:30-42): mean |wz| times the weight
+        if (tw_on) ext = fmaf(fabsf(wz), k_tw, ext);
+      }
       if (ga_on) {
         // GoalAngleCritic (goal_angle_critic.cpp:36-50), near-goal ticks only (a uniform branch):
         // |normalize_angles(goal yaw - yaw)|.  The reference normalises in double; here the
@@ -887,10 +913,19 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     float lin = 0.f, uni = 0.f;
     if (OBST) {
       const bool collided = alive == 0.f;
-      lin = (collided ? 0.f : p.obs_critical_w * crit) + p.obs_rep_over_T * rep;
-      uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+      if (cost_mode) {
+        // cost_critic.cpp:157-166: collision_cost for a colliding rollout, else the sum of the
+        // per-cost terms, times weight / 254 / T
+        const float k = p.cost_w254 / (float)T;
+        lin = collided ? 0.f : k * rep;
+        uni = collided ? k * p.cost_collision_cost : 0.f;
+      } else {
+        lin = (collided ? 0.f : p.obs_critical_w * crit) + p.obs_rep_over_T * rep;
+        uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+      }
       n_noncoll += (uint32_t)__popcll(__ballot(live && !collided));
     }
+    if constexpr (DEP) lin += ext;
     if (p.flags & SD_PATH_FOLLOW) {
       const float fdx = x - pf_x, fdy = y - pf_y;
       uni += p.pf_weight * fast_sqrt(fdx * fdx + fdy * fdy);
@@ -1053,7 +1088,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
 hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, uint32_t block, hipStream_t st)
 {
   if (!rr && block != LANE_BLOCK && block != LANE_BLOCK / 2) return hipErrorInvalidValue;
-  const bool obst = (p.flags & SD_OBSTACLES) != 0;
+  const bool obst = (p.flags & (SD_OBSTACLES | SD_COST)) != 0;   // (Cost: the deployed-list instances, same lookup)
   if (rr) {
     // whole chunks only (T = 64 or 128): the ragged instances spill registers, and a spill in
     // the time loop costs the noise prefetch its depth (every scratch access waits vmcnt(0))
@@ -1067,6 +1102,18 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
     return hipGetLastError();
   }
   const bool full = p.T == 64u;
+  if (p.flags & (SD_CONSTRAINT | SD_COST | SD_TWIRLING)) {   // cruise tick of the deployed critic list
+    if (!obst || (p.flags & (SD_GOAL_ANGLE | SD_GOAL)) || ((p.flags & SD_COST) && (p.flags & SD_OBSTACLES)) ||
+        p.con_acker_r >= 0.f || (!full && p.T != 56u))
+      return hipErrorInvalidValue;
+    if (full)
+      hipLaunchKernelGGL((smpc_pass_lane<true, true, false, 1, false, false, true, 0, true>), dim3(grid), dim3(block), L.total,
+                         st, p, L, static_cast<const SmpcDev*>(nullptr));
+    else
+      hipLaunchKernelGGL((smpc_pass_lane<false, true, false, 1, false, false, true, 56, true>), dim3(grid), dim3(block), L.total,
+                         st, p, L, static_cast<const SmpcDev*>(nullptr));
+    return hipGetLastError();
+  }
   if (p.flags & SD_GOAL_ANGLE) {   // near-goal tick: the instances with the GoalAngle term
     if (!obst) return hipErrorInvalidValue;
 #define SMPC_LANE_LAUNCH_GA(F) \
@@ -1131,7 +1178,9 @@ static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8
     case 10: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, true>);   // near-goal
     case 11: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, true>);
     case 12: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true>);   // whole quads
-    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56>);   // T = 56
+    case 13: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56>);   // T = 56
+    case 14: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, false, true, 0, true>);   // deployed list
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56, true>);
   }
 }
 
@@ -1150,7 +1199,7 @@ hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_pe
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 14 && e == hipSuccess; ++k)
+  for (int k = 0; k < 16 && e == hipSuccess; ++k)
     e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }

@@ -84,14 +84,28 @@ static float distance_to_obstacle(const HostCostmap& m, float cost, bool using_f
 
 // consider_fp: the critic's consider_footprint collision rule; using_fp: the cost came from the
 // footprint (no inscribed-radius offset, obstacles_critic.cpp:106-108)
+// cost_terms (non-null: CostCritic scored WITHOUT ObstaclesCritic): the table's second field is the
+// CostCritic's per-cost term (cost_critic.cpp:141-155) instead of ObstaclesCritic's repulsion — the
+// first field keeps the shared collision marker and is otherwise zero — so that the lane pass's
+// lookup pipeline scores CostCritic as it stands; the wave pass reads only the marker then
 static void build_lut(const smpc_ctx* c, bool near_goal, SmpcLut* lut, bool consider_fp = false,
-               bool using_fp = false)
+               bool using_fp = false, const float* cost_terms = nullptr)
 {
   const auto& m = c->map;
   const auto& p = c->critics.obstacles;
   for (int v = 0; v < 256; ++v) {
     lut[v].crit = 0.f;
     lut[v].rep = 0.f;
+    if (cost_terms) {
+      if (v == SMPC_COST_LETHAL || (v == SMPC_COST_INSCRIBED && !consider_fp) ||
+        (v == SMPC_COST_NO_INFORMATION && !m.track_unknown))
+      {
+        lut[v].crit = -1.0f;
+      } else {
+        lut[v].rep = cost_terms[v];
+      }
+      continue;
+    }
     // inCollision (obstacles_critic.cpp:185-201), consider_footprint = false
     if (v == SMPC_COST_LETHAL || (v == SMPC_COST_INSCRIBED && !consider_fp) ||
       (v == SMPC_COST_NO_INFORMATION && !m.track_unknown))
@@ -399,8 +413,15 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   c->grid = std::max(1u, std::min(grid, kMaxGrid));
   // the lane-per-rollout pass scores the north star's five, GoalAngle (power 1) included
   // (its GoalAngle instances: the parking form with ObstaclesCritic scored, T <= 64)
-  const bool lane_mode = mode_now == 0 ||
-    (mode_now == 3 && !(gates & (lean_extra & ~SD_GOAL_ANGLE)) && (gates & SD_OBSTACLES) && T <= 64);
+  const bool lane_ga = mode_now == 3 && !(gates & (lean_extra & ~SD_GOAL_ANGLE)) && (gates & SD_OBSTACLES) && T <= 64;
+  // (its deployed-list instances, DEP: Constraint / Cost / Twirling on a cruise tick — Goal and
+  // GoalAngle gated off, PathAngle inside its angle for every candidate furthest point, Cost
+  // without Obstacles next to it, no Ackermann term, T = 64 or the default 56)
+  const uint32_t dep_set = SD_CONSTRAINT | SD_COST | SD_TWIRLING;
+  const bool lane_dep = mode_now == 3 && (gates & dep_set) && !(gates & (SD_GOAL | SD_GOAL_ANGLE)) &&
+    !((gates & SD_PATH_ANGLE) && c->pang_any) && !((gates & SD_COST) && (gates & SD_OBSTACLES)) &&
+    (gates & (SD_COST | SD_OBSTACLES)) && c->acker_r < 0.f && (T == 64 || T == 56);
+  const bool lane_mode = mode_now == 0 || lane_ga || lane_dep;
   c->lane_now = c->use_tpr && lane_mode && T <= kLaneMaxT;
   // the lane pass samples PathAlign's trajectory points at the first step of every quad:
   // trajectory_point_step = 4, the reference's default (path_align_critic.cpp:36)
@@ -597,6 +618,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
 
   uint8_t* pang_active = h + tl.pang_active;
   bool pang_correct = false;
+  c->pang_any = false;     // PathAngleCritic live for some candidate furthest point this tick
   if (gates & SD_PATH_ANGLE) {
     // path_angle_critic.cpp:24-31,52-54: reversing / forward preference
     bool reversing_allowed = true;
@@ -624,6 +646,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
         ang = static_cast<float>(std::min(std::fabs(norm(pyaw0 - static_cast<double>(yaw))), b));
       }
       pang_active[S] = ang < cr.path_angle.max_angle_to_furthest ? 0 : 1;
+      if (pang_active[S]) c->pang_any = true;
     }
   } else {
     memset(pang_active, 0, std::max(P, 1u));
@@ -649,10 +672,11 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // ---- Obstacles LUT: rebuilt and uploaded only when its inputs changed -----------
   if (gates & (SD_OBSTACLES | SD_COST)) {
     const bool near_goal = within_tol(cr.obstacles.near_goal_distance, rx, ry, gx, gy);  // :124-127
-    const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 2) ^ (near_goal ? 1u : 0u) ^
-      ((gates & (SD_FP_OBSTACLES | SD_FP_COST)) ? 2u : 0u);
+    const bool cost_only = (gates & SD_COST) && !(gates & SD_OBSTACLES) && !(gates & (SD_FP_OBSTACLES | SD_FP_COST));
+    const uint64_t key = (c->map_version << 20) ^ (c->critics_version << 4) ^ (near_goal ? 1u : 0u) ^
+      ((gates & (SD_FP_OBSTACLES | SD_FP_COST)) ? 2u : 0u) ^ (cost_only ? 4u : 0u) ^ (near_goal_cost ? 8u : 0u);
     if (!c->lut_valid || key != c->lut_key) {
-      build_lut(c, near_goal, c->h_lut);
+      build_lut(c, near_goal, c->h_lut, false, false, cost_only ? lut_cost : nullptr);
       HIPCK(c, hipMemcpyAsync(c->d_lut, c->h_lut, 256 * sizeof(SmpcLut), hipMemcpyHostToDevice,
                               c->stream));
       if (gates & (SD_FP_OBSTACLES | SD_FP_COST)) {

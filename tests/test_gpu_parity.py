@@ -406,7 +406,48 @@ def test_other_registered_critics_parity(Smpc, Oracle, names, power, near, B, T)
     assert og.non_colliding == oo.non_colliding
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
                   label=f"critics {names} power {power} near {near}")
-    assert og.pass_kind == 0       # the general wave-per-rollout pass scores these
+    # the wave-per-rollout pass scores these (lean MODE 3 or the general pass); a cruise tick of
+    # Constraint / Cost / Twirling with power 1 at a lane-pass batch takes that pass's deployed-list
+    # instances (test_deployed_list_cruise_tick_on_the_lane_pass)
+    assert og.pass_kind == (1 if B >= 60000 else 0)
+
+
+@pytest.mark.parametrize("B,T,names", [
+    (70000, 64, DEPLOYED), (70000, 56, DEPLOYED), (8192, 64, DEPLOYED), (4096, 56, DEPLOYED),
+    (8192, 64, ("cost", "path_align", "path_follow", "prefer_forward")),
+    (8192, 64, ("obstacles", "constraint", "twirling", "path_align", "path_follow", "prefer_forward")),
+])
+def test_deployed_list_cruise_tick_on_the_lane_pass(Smpc, Oracle, B, T, names):
+    """The reference's deployed critic list (robot_bringup/config/nav2_params.yaml:222) on a cruise
+    tick — away from the goal (Goal and GoalAngle gated off), the robot pointing along the path
+    (PathAngle inside its angle) — takes the lane-per-rollout pass's deployed-list instances:
+    CostCritic in ObstaclesCritic's place in the lookup pipeline, Constraint and Twirling as
+    per-step terms.  Against the oracle, closed loop of three ticks; and the wave pass (MODE 3)
+    gives the same tick within float reassociation."""
+    cfg, scn, noise = make_case(B, T)
+    cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+    cr = _extra_critics(names)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, critics=cr, noise=noise)
+    cfg_w = default_config(batch_size=B, time_steps=T)
+    cfg_w.flags &= ~A.SMPC_FLAG_LANE_PER_ROLLOUT
+    w = Smpc(cfg_w) if B < 60000 else None      # (below the lane pass's default threshold: the wave pass)
+    if w is not None:
+        configure(w, scn, critics=cr, noise=noise)
+    u = scn.u0
+    for k in range(3):
+        ug, og = g.optimize(scn.tick, u)
+        uo, oo = o.optimize(scn.tick, u)
+        assert og.pass_kind == 1, "not the lane pass"
+        assert og.non_colliding == oo.non_colliding and og.fail_flag == oo.fail_flag
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2,
+                      label=f"deployed list on the lane pass {B}x{T} {len(names)} critics tick {k}")
+        if w is not None:
+            uw, ow = w.optimize(scn.tick, u)
+            assert ow.pass_kind == 0
+            assert rel_err(ug, uw) < 5e-6
+        u = np.concatenate([uo[:, 1:], uo[:, -1:]], axis=1)
 
 
 @pytest.mark.parametrize("lane", [False, True])
