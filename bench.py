@@ -678,6 +678,8 @@ def main():
                     time_config(B, T, MAP, k4, 3, redraw=True),
                 "deployed configuration 2000x56, the nine critics of nav2_params.yaml:222":
                     time_config(2000, 56, MAP, 4 * args.steps, 40, critics=DEPLOYED_CRITICS),
+                f"the deployed nine critics and horizon at the metric's batch, {B}x56":
+                    time_config(B, 56, MAP, k4, 3, critics=DEPLOYED_CRITICS),
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, MAP)
