@@ -61,7 +61,7 @@ hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu
 hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_per_cu);
 hipError_t smpc_lane_set_lds_limit(int bytes);
 hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
-hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
+hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst, bool dep, uint32_t T,
                                       const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
                                    float neg_inv_temp, hipStream_t st);

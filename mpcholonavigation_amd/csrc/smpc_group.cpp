@@ -109,7 +109,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
   // ---- prepare every member; decide whether the batched launch applies -----------------
   bool batched = true;
   uint32_t Pmax = 0, window_bytes = 0, gridx = 0;
-  bool obst = false;
+  bool obst = false, dep = false;
   std::vector<uint32_t> flags(n);
   for (uint32_t i = 0; i < n; ++i) {
     smpc_ctx* c = g->ctxs[i];
@@ -122,17 +122,18 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     flags[i] = scoring_flags(c, c->fail_in);
     const bool need_f = (flags[i] & SD_NEED_FURTHEST) != 0;
     if (need_f) flags[i] |= SD_LOCAL_FURTHEST;
-    // (a near-goal member scores GoalAngle, a member with the deployed critic list Constraint / Cost /
-    // Twirling: instances of the lane pass the batched launch does not have)
-    const bool ok = c->lane_now && !c->lane_rr && !(flags[i] & (SD_GOAL_ANGLE | SD_CONSTRAINT | SD_COST | SD_TWIRLING)) &&
+    // (a near-goal member scores GoalAngle: instances of the lane pass the batched launch does not
+    // have; members with the deployed critic list — Constraint / Cost / Twirling — have theirs)
+    if (flags[i] & (SD_CONSTRAINT | SD_COST | SD_TWIRLING)) dep = true;
+    const bool ok = c->lane_now && !c->lane_rr && !(flags[i] & SD_GOAL_ANGLE) &&
       c->cfg.iteration_count == 1 && !c->fail_in &&
       !(c->cfg.flags & (SMPC_FLAG_NO_SPECULATION | SMPC_FLAG_PROFILE)) && (!need_f || c->hint_valid) &&
       c->poll_enabled && c->acker_r < 0.f;
     if (!ok) batched = false;
     if (i == 0) {
       window_bytes = c->lane_window_bytes;
-      obst = (flags[i] & SD_OBSTACLES) != 0;
-    } else if (c->lane_window_bytes != window_bytes || ((flags[i] & SD_OBSTACLES) != 0) != obst ||
+      obst = (flags[i] & (SD_OBSTACLES | SD_COST)) != 0;    // (either one: the costmap lookups)
+    } else if (c->lane_window_bytes != window_bytes || ((flags[i] & (SD_OBSTACLES | SD_COST)) != 0) != obst ||
                c->lane_block != c0->lane_block) {
       batched = false;
     }
@@ -170,7 +171,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
   }
   HIPCK(c0, hipMemcpyAsync(g->d_all, g->h_all, g->total, hipMemcpyHostToDevice, g->stream));
   HIPCK(c0, smpc_launch_pass_lane_many(reinterpret_cast<const SmpcDev*>(g->d_all + g->off_dev), n,
-                                       T == 64, obst, L, gridx, c0->lane_block, g->stream));
+                                       T == 64, obst, dep, T, L, gridx, c0->lane_block, g->stream));
   HIPCK(c0, smpc_launch_reduce_many(reinterpret_cast<const SmpcReduceArgs*>(g->d_all + g->off_red), n,
                                     T, c0->dev.neg_inv_temp, g->stream));
   g->batched_ticks++;

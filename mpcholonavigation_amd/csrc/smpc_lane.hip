@@ -279,7 +279,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // same costAtPose, same collision rule, its per-cost term in the table's second field — and
   // Constraint and Twirling are two more additive per-step terms (power 1, in float like the
   // other sums of this pass).  Instances of their own: the cruise instances of the five pay nothing.
-  static_assert(!DEP || (OBST && !RR && !MANY && !GA), "deployed-list instances: parking form, single instance");
+  static_assert(!DEP || (OBST && !RR && !GA), "deployed-list instances: parking form");
   const SmpcDev& p = MANY ? many[blockIdx.y] : p0;
   // (this pass reads its tick block from device memory only: it fetches u with scalar loads quad
   // by quad, group after group, and reads of the kernarg segment are not cached the way plain
@@ -1143,11 +1143,23 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
 
 // n planning instances (same T, same critic set) in one launch; d_many: their parameter
 // blocks in device memory
-hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst,
+// dep: some instance scores Constraint / Cost / Twirling (the deployed critic list's cruise tick):
+// the DEP instances, T = 64 (full) or 56; an instance without those critics runs them unchanged
+hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst, bool dep, uint32_t T,
                                       const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st)
 {
   if (block != LANE_BLOCK && block != LANE_BLOCK / 2) return hipErrorInvalidValue;
   const SmpcDev none{};
+  if (dep) {
+    if (!obst || (!full && T != 56u)) return hipErrorInvalidValue;
+    if (full)
+      hipLaunchKernelGGL((smpc_pass_lane<true, true, true, 1, false, false, true, 0, true>), dim3(grid, n), dim3(block), L.total,
+                         st, none, L, d_many);
+    else
+      hipLaunchKernelGGL((smpc_pass_lane<false, true, true, 1, false, false, true, 56, true>), dim3(grid, n), dim3(block), L.total,
+                         st, none, L, d_many);
+    return hipGetLastError();
+  }
 #define SMPC_LANE_LAUNCH(F, O) \
   hipLaunchKernelGGL((smpc_pass_lane<F, O, true, 1, false>), dim3(grid, n), dim3(block), L.total, st, none, L, \
                      d_many)
@@ -1164,7 +1176,7 @@ uint32_t smpc_lane_block_rr() {return LANE_BLOCK_RR;}
 
 static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8, 9: re-read with one, two chunks; 10, 11: GoalAngle
 {
-  switch (k & 15) {
+  switch (k) {
     case 0: return reinterpret_cast<const void*>(&smpc_pass_lane<false, false, false, 1, false>);
     case 1: return reinterpret_cast<const void*>(&smpc_pass_lane<true, false, false, 1, false>);
     case 2: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false>);
@@ -1180,7 +1192,9 @@ static const void* lane_kernel(int k)   // bit 0 FULL, bit 1 OBST, bit 2 MANY; 8
     case 12: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true>);   // whole quads
     case 13: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56>);   // T = 56
     case 14: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, false, 1, false, false, true, 0, true>);   // deployed list
-    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56, true>);
+    case 15: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, false, 1, false, false, true, 56, true>);
+    case 16: return reinterpret_cast<const void*>(&smpc_pass_lane<true, true, true, 1, false, false, true, 0, true>);    // ... grouped
+    default: return reinterpret_cast<const void*>(&smpc_pass_lane<false, true, true, 1, false, false, true, 56, true>);
   }
 }
 
@@ -1199,7 +1213,7 @@ hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_pe
 hipError_t smpc_lane_set_lds_limit(int bytes)
 {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 16 && e == hipSuccess; ++k)
+  for (int k = 0; k < 18 && e == hipSuccess; ++k)
     e = hipFuncSetAttribute(lane_kernel(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }
