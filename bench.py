@@ -113,7 +113,7 @@ def raise_clocks(g, ms, seed=1234):
     redraw kernel (compute-bound, the product's own), then the seed again — the stored noise is
     bit for bit what it was.  From idle the shader clock takes ~150 ms of load to climb from 2.0
     to 2.34 GHz (rocm-smi samples: tools/clock_watch.py), so the first ~60 ticks of a fresh
-    process run 10-20 % slower than the rest (tools/ramp.py, tools/warm_test.py: ticks 5-24 take
+    process run 10-20 % slower than the rest (tools/ramp.py, tools/warm_ticks.py: ticks 5-24 take
     481 us cold, 419 us behind this; steady state ~410).  The metric is steady-state throughput:
     a run of 5 + 20 ticks should measure what a run of 100 + 200 measures.  W and K are untouched."""
     if ms <= 0:
@@ -649,7 +649,7 @@ def main():
                 "what": "device-RNG redraw kernels in front of the W warm-up ticks, then the seed again (the stored "
                         "noise is unchanged); --clock-warmup-ms 0 turns it off.  From idle the shader clock climbs "
                         "from 2.0 to 2.34 GHz over ~150 ms of load (tools/clock_watch.py): without this, ticks 5-24 of a "
-                        "fresh process take 481 us, behind it 419 us, in steady state ~410 us (tools/warm_test.py)",
+                        "fresh process take 481 us, behind it 419 us, in steady state ~410 us (tools/warm_ticks.py)",
             },
             "moving_pose": {
                 "ms_per_step": 1e3 * el_mv / args.steps,

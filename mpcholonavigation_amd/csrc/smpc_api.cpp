@@ -121,18 +121,27 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   const bool prof = (c->cfg.flags & SMPC_FLAG_PROFILE) && c->evp_used + 2 <= 8;
   if (prof) HIPCK(c, hipEventRecord(c->evp[c->evp_used], c->stream));
   uint32_t nblk = c->grid;
-  const bool lane = c->lane_now && !(flags & SD_STORE_TRAJ);
+  // The re-read form has instances with a collision critic scored only.  A tick whose flags were
+  // stripped after the launch was planned — fail_flag_in (the retry after fallback(), which scores
+  // nothing: critic_manager.cpp:70-73) or the later iterations of an all-collide tick — takes the
+  // wave-per-rollout pass instead (its geometry is planned for every tick).
+  const bool lane = c->lane_now && !(flags & SD_STORE_TRAJ) &&
+    !(c->lane_rr && !(flags & (SD_OBSTACLES | SD_COST)));
   if (lane) nblk = c->grid_tpr;
   // The block that finishes last reduces the partials inside the scoring launch (smpc_tail.h);
   // larger grids, and launches whose LDS was not sized for it, take the separate reduction.
-  if (c->poll_words > kPollWords) return fail(c, SMPC_ERR_UNSUPPORTED, "time_steps beyond the completion words");
   const bool tail = c->fused_reduce && nblk <= SMPC_TAIL_MAX_GRID && (!lane || c->lane_block == smpc_lane_block()) &&
     (lane ? c->lds_tpr.total : c->lds.total) >= smpc_tail_lds_bytes(d.T);
   // completion words: one per block of smpc_reduce_partials, or per reducing block of the tail
   c->poll_words = (fin.enabled && fin.done_counter) ? (4u + 3u * d.T + 31u) / 32u : 0u;
+  static_assert((4u + 3u * 64u * SMPC_MAX_R + 31u) / 32u <= kPollWords, "one completion word per reducing block");
   if (tail) {
     // (every reducing block publishes its own completion word: smpc_tail.h)
     if (fin.enabled && fin.done_counter) c->poll_words = std::min((4u + 3u * d.T + 63u) / 64u, nblk);
+    // the tail's "gave up waiting" mark of an earlier tick must not fail this one (no launch of
+    // this ctx is in flight here: every tick ends with fetch_out); the mailbox exchange's mark
+    // in the same word is sticky by design and stays
+    if (c->h_out[3 * d.T + 6] == 2.0f) c->h_out[3 * d.T + 6] = 0.0f;
     d.tail = 1;
     d.tail_counter = reinterpret_cast<uint32_t*>(c->d_furthest) + 4;
     d.tuple = d_tuple;

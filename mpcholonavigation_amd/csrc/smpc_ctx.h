@@ -248,7 +248,8 @@ struct smpc_ctx {
   float hint_F = 0.f;
   float hint_Fp = 0.f;       // the last prediction, unrounded; valid when hint_Fp_valid
   bool hint_Fp_valid = false;
-  smpc_tick_in step_in{};       // step-wise sharded API: this tick's inputs (smpc_shard_begin .. smpc_shard_combine)
+  smpc_tick_in step_in{};       // step-wise sharded API: this tick's inputs (smpc_shard_begin .. smpc_shard_combine),
+  std::vector<float> step_px, step_py;   // with the path it points at copied here
   bool step_remembered = false;
   bool hint_is_this_ticks = false;   // set by the group's re-run of a missed member (predict_hint)
   float hint_drift = 0.f;    // last tick's (true - predicted): how fast the endpoints drift relative to the robot

@@ -217,7 +217,7 @@ __device__ __forceinline__ SmpcTickPtrs smpc_tick_ptrs(const SmpcDev& p, bool ke
 // exchange between GPUs and the float slot of the tuple work on F unchanged; every consumer of
 // the INDEX rounds.  The fraction only feeds the host's prediction of the next tick's index
 // (smpc_prepare.cpp predict_hint): a wrong prediction costs a re-score, never a wrong result.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline uint32_t smpc_furthest_index(float F) {return (uint32_t)(F + 0.5f);}

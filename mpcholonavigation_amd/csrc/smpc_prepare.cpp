@@ -379,8 +379,10 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   }
   c->lds = make_lds(window_bytes, P, T, (pass_block(c->R) / 64), window_bytes != 0, nsamp);
   if (c->lds.total > kLdsPerCu) return fail(c, SMPC_ERR_UNSUPPORTED, "LDS budget exceeded");
-  // room for the reduction inside the scoring launch (smpc_tail.h works in the launch's LDS)
-  c->lds.total = std::max(c->lds.total, smpc_tail_lds_bytes(T));
+  // room for the reduction inside the scoring launch (smpc_tail.h works in the launch's LDS) —
+  // only for contexts that run that experiment: for 128 < T <= 256 the padding would halve the
+  // wave pass's blocks per CU
+  if (c->fused_reduce) c->lds.total = std::max(c->lds.total, smpc_tail_lds_bytes(T));
 
   // persistent grid: as many blocks as stay resident, never more than the work
   const uint32_t waves_per_block = (pass_block(c->R) / 64);
@@ -437,7 +439,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     c->lds_tpr = Lt;
     if (Lt.total > kLdsPerCu) c->lane_now = false;   // long paths: the parked wz no longer fits
     // (the re-read form: no in-launch reduction, smpc_lane.hip)
-    if (!c->lane_rr) c->lds_tpr.total = std::max(Lt.total, smpc_tail_lds_bytes(T));
+    if (!c->lane_rr && c->fused_reduce) c->lds_tpr.total = std::max(Lt.total, smpc_tail_lds_bytes(T));
   }
   if (c->lane_now) {
     const uint32_t lblock = c->lane_rr ? smpc_lane_block_rr() : smpc_lane_block();

@@ -49,10 +49,20 @@ int smpc_shard_begin(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   c->passes = 0;
   c->evp_used = 0;
   c->costs_cur = 0;
-  // (the caller keeps *in and its arrays alive until the tick's last smpc_shard_combine)
+  const int rc = prepare_tick(c, in, u_in);
+  if (rc != SMPC_OK) return rc;
+  // What smpc_shard_combine hands to the furthest-point predictor, copied: the caller owns *in
+  // and its arrays and may free or reuse them as soon as this call returns (include/smpc.h:
+  // "the library copies before returning and never retains host pointers").
   c->step_in = *in;
+  c->step_px.assign(in->path_x, in->path_x + in->path_len);
+  c->step_py.assign(in->path_y, in->path_y + in->path_len);
+  c->step_in.path_x = c->step_px.data();
+  c->step_in.path_y = c->step_py.data();
+  c->step_in.path_yaw = nullptr;          // (not read after this call)
+  c->step_in.path_pts_valid = nullptr;
   c->step_remembered = false;
-  return prepare_tick(c, in, u_in);
+  return SMPC_OK;
 }
 
 int smpc_shard_predicted_furthest(smpc_ctx* c, uint32_t* hint)

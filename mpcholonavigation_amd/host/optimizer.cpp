@@ -150,6 +150,10 @@ void Optimizer::initialize(
     ctx_ = keep;
     keep = nullptr;
     ck(ctx_, smpc_set_critics(ctx_, &critics_.params), "smpc_set_critics");
+    // as a fresh context: noise supplied through setNoise() does not survive initialize(), and the
+    // draw starts from the seed's first epoch again (same seed, same noise as a new object)
+    supplied_noise_ = false;
+    ck(ctx_, smpc_seed(ctx_, noise_seed_), "smpc_seed");
     reset();
     return;
   }
@@ -158,6 +162,7 @@ void Optimizer::initialize(
     keep = nullptr;
   }
   have_built_ = false;
+  supplied_noise_ = false;
   int rc = smpc_create(&cfg, &ctx_);
   if (rc != SMPC_OK) {
     throw std::runtime_error(std::string("smpc_create: ") + smpc_last_error(nullptr));

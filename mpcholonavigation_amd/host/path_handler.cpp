@@ -53,7 +53,7 @@ size_t first_after_integrated_distance(const std::vector<Pose2> & v, size_t begi
 
 unsigned int findFirstPathInversion(const std::vector<Pose2> & path)
 {
-  // At least 3 poses for a possible inversion
+  // (two segments are the least a direction change needs: shorter paths have none, :617-620)
   if (path.size() < 3) {
     return static_cast<unsigned int>(path.size());
   }
@@ -114,7 +114,7 @@ std::vector<Pose2> PathHandler::getGlobalPlanConsideringBoundsInCostmapFrame(
   const Pose2 & global_pose, const Transform2 & plan_to_costmap, size_t & closest)
 {
   const std::vector<Pose2> & plan = global_plan_up_to_inversion_;
-  // Limit the search for the closest pose up to max_robot_pose_search_dist on the path
+  // the nearest pose is looked for only within max_robot_pose_search_dist of path length from the start (:56-61)
   const size_t upper = first_after_integrated_distance(plan, 0, plan.size(), p_.max_robot_pose_search_dist);
   // nav2_util::geometry_utils::min_by: the first minimum
   closest = 0;
@@ -174,7 +174,7 @@ Pose2 PathHandler::getTransformedGoal(const Transform2 & plan_to_costmap) const
 
 bool PathHandler::isWithinInversionTolerances(const Pose2 & robot_pose) const
 {
-  // Keep full path if we are within tolerance of the inversion pose
+  // close enough to the inversion pose, in position and heading: the rest of the plan comes back (:209-216)
   const Pose2 & last_pose = global_plan_up_to_inversion_.back();
   const float distance = hypotf(
     static_cast<float>(robot_pose.x - last_pose.x), static_cast<float>(robot_pose.y - last_pose.y));

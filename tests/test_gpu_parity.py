@@ -114,6 +114,29 @@ def test_all_collide_sets_fail_flag(Smpc, Oracle, both_passes):
     assert_parity(ug2, og2, uo2, oo2, g.get_costs(), o.get_costs(), label="sticky fail")
 
 
+@pytest.mark.parametrize("iterations", [1, 2])
+def test_all_collide_on_the_reread_form(Smpc, Oracle, iterations):
+    """T = 128 on the lane pass's re-read form, which has instances with a collision critic
+    scored only: the retry after fallback() (fail_flag_in: nothing is scored,
+    critic_manager.cpp:70-73) and the later iterations of an all-collide tick (flags stripped the
+    same way) must run — on the wave pass — not fail with a device error."""
+    cfg, scn, noise = make_case(1024, 128, all_lethal=True)
+    cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+    cfg.iteration_count = iterations
+    g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
+    assert og.fail_flag == 1 and oo.fail_flag == 1
+    assert og.non_colliding == 0
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"all collide T=128 it={iterations}")
+    t = scn.tick
+    t2 = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw, t.goal_x,
+              t.goal_y, fail_flag_in=True)
+    u0 = np.zeros_like(scn.u0)
+    ug2, og2 = g.optimize(t2, u0)
+    uo2, oo2 = o.optimize(t2, u0)
+    assert og2.fail_flag == 1 and oo2.fail_flag == 1
+    assert_parity(ug2, og2, uo2, oo2, g.get_costs(), o.get_costs(), label=f"sticky fail T=128 it={iterations}")
+
+
 def test_two_iterations_accumulate_costs(Smpc, Oracle, both_passes):
     """iteration_count=2: costs accumulate, furthest point cached."""
     cfg, scn, noise = make_case(2000, 56)

@@ -117,6 +117,56 @@ def test_stepwise_sharded_tick_uses_the_library_prediction():
     assert so.rescored <= 4
 
 
+def test_shard_begin_copies_what_it_keeps():
+    """smpc_shard_begin retains no caller pointer (include/smpc.h ownership rule): the
+    path arrays may be overwritten as soon as it returns, and the furthest-point predictor fed by
+    smpc_shard_combine still anchors on the path the tick was scored with."""
+    from bench import MovingScene, shift
+    from mpcholonavigation_amd.optimizer import Smpc
+    from mpcholonavigation_amd.tick import Tick
+    B, T = 4096, 64
+    scn = make_scenario(T)
+    noise = make_noise(B, T)
+    dev = torch.device("cuda", 0)
+    cfg = default_config(batch_size=B, time_steps=T)
+    ctxs = [_mk(Smpc, cfg, scn, noise, slice(0, B)) for _ in range(2)]
+    L = ctxs[0].tuple_len
+    t_all = torch.zeros(L, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for c in ctxs:
+        c.set_stream(stream)
+    mv = MovingScene(scn, cfg.model_dt)
+    u = scn.u0
+    hints = [[], []]
+    for k in range(6):
+        base = mv.tick()
+        res = []
+        for i, c in enumerate(ctxs):
+            tk = Tick(base.pose_x, base.pose_y, base.pose_yaw, base.speed, base.path_x.copy(), base.path_y.copy(),
+                      base.path_yaw.copy(), base.goal_x, base.goal_y)
+            c.shard_begin(tk, u)
+            if i == 1:            # the caller reuses its buffers right after begin
+                tk.path_x[:] = np.nan
+                tk.path_y[:] = -1.0e30
+                tk.path_yaw[:] = np.nan
+            h = c.shard_predicted_furthest()
+            hints[i].append(h)
+            t_f = torch.zeros(1, dtype=torch.float32, device=dev)
+            if h is None:
+                c.shard_furthest(t_f.data_ptr())
+                c.shard_score(t_f.data_ptr(), 0, t_all.data_ptr())
+            else:
+                c.shard_score(0, h, t_all.data_ptr())
+            res.append(c.shard_combine(t_all.data_ptr(), 1))
+        (u0_, o0), (u1_, o1) = res
+        assert np.array_equal(u0_, u1_), k
+        assert o0.furthest_reached_path_point == o1.furthest_reached_path_point, k
+        mv.advance(u0_)
+        u = shift(u0_)
+    assert hints[0] == hints[1], hints
+    assert any(h is not None for h in hints[0])
+
+
 def test_gpu_shard_rng_is_a_slice_of_the_global_stream():
     from mpcholonavigation_amd.optimizer import Smpc
     B, T = 200, 33
