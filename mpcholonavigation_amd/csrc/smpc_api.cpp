@@ -9,6 +9,8 @@
 
 #include "smpc_ctx.h"
 
+#include <emmintrin.h>
+
 namespace smpc_impl {
 
 thread_local std::string g_create_error;
@@ -29,6 +31,62 @@ int wait_map_upload(smpc_ctx* c)
   HIPCK(c, hipEventSynchronize(c->ev_map));
   c->map_pending = false;
   return SMPC_OK;
+}
+
+void bar_copy(void* dev_dst, const void* host_src, size_t n)
+{
+  // The BAR mapping is write-combining: 16-byte streaming stores fill whole 64-byte buffers,
+  // and the fence drains them before any later store of this thread — the runtime's doorbell
+  // write for the launch that reads the block included (PCIe keeps posted writes to one device
+  // in order).  The kernel boundary in front of that launch invalidates the GPU's caches.
+  const __m128i* src = static_cast<const __m128i*>(host_src);
+  __m128i* dst = static_cast<__m128i*>(dev_dst);
+  for (size_t i = 0; i < n / 16; ++i) _mm_stream_si128(dst + i, _mm_load_si128(src + i));
+  _mm_sfence();
+}
+
+void bar_flush(const smpc_ctx* c)
+{
+  // one posted MMIO write, ordered behind the drained stores and in front of the doorbell
+  if (c->hdp_flush) *c->hdp_flush = 1u;
+}
+
+// HDP_MEM_FLUSH_CNTL of HIP device `dev` (matched by PCI location), through the HSA runtime the
+// HIP runtime already holds; null when it cannot be found
+static volatile uint32_t* find_hdp_flush(int dev)
+{
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+  void* h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return nullptr;
+  using agent_t = struct {uint64_t handle;};
+  using iterate_fn = int (*)(int (*)(agent_t, void*), void*);
+  using info_fn = int (*)(agent_t, int, void*);
+  using init_fn = int (*)();
+  static init_fn p_init = reinterpret_cast<init_fn>(dlsym(h, "hsa_init"));
+  static iterate_fn p_iter = reinterpret_cast<iterate_fn>(dlsym(h, "hsa_iterate_agents"));
+  static info_fn p_info = reinterpret_cast<info_fn>(dlsym(h, "hsa_agent_get_info"));
+  if (!p_init || !p_iter || !p_info || p_init() != 0) return nullptr;   // (reference-counted; HIP holds it already)
+  struct Want {
+    uint32_t domain, bdf;
+    volatile uint32_t* reg;
+  } want{static_cast<uint32_t>(prop.pciDomainID),
+         (static_cast<uint32_t>(prop.pciBusID) << 8) | (static_cast<uint32_t>(prop.pciDeviceID) << 3), nullptr};
+  auto cb = [](agent_t a, void* data) -> int {
+    Want* w = static_cast<Want*>(data);
+    int type = 0;   // HSA_AGENT_INFO_DEVICE = 17, HSA_DEVICE_TYPE_GPU = 1
+    if (p_info(a, 17, &type) != 0 || type != 1) return 0;
+    uint32_t bdf = 0, domain = 0;
+    if (p_info(a, 0xA006, &bdf) != 0) return 0;              // HSA_AMD_AGENT_INFO_BDFID
+    if (p_info(a, 0xA00F, &domain) != 0) domain = w->domain;   // HSA_AMD_AGENT_INFO_DOMAIN
+    if ((bdf & ~7u) != w->bdf || domain != w->domain) return 0;
+    struct {uint32_t* mem; uint32_t* reg;} f{nullptr, nullptr};
+    if (p_info(a, 0xA00E, &f) == 0) w->reg = f.mem;          // HSA_AMD_AGENT_INFO_HDP_FLUSH
+    return 1;   // (HSA_STATUS_INFO_BREAK: stop iterating)
+  };
+  (void)p_iter(cb, &want);
+  return want.reg;
 }
 
 void free_ctx(smpc_ctx* c)
@@ -72,6 +130,7 @@ int launch_furthest(smpc_ctx* c, float* d_furthest)
   d.flags = c->gate_flags & SD_NEED_FURTHEST;
   d.furthest_out = reinterpret_cast<uint32_t*>(d_furthest);
   SmpcLds L = make_lds(0, c->P, d.T, (pass_block(c->R) / 64), false);
+  c->launched = true;
   HIPCK(c, smpc_launch_pass(c->R, 1, d, L, c->grid, pass_block(c->R), c->stream));
   return SMPC_OK;
 }
@@ -147,6 +206,7 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
     d.tuple = d_tuple;
     d.fin = fin;
   }
+  c->launched = true;
   // the lane-per-rollout pass scores with the full lean critic stack only
   if (lane) {
     HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->lane_rr, c->lane_block, c->stream));
@@ -199,6 +259,22 @@ void store_control_sequence(const smpc_ctx* c, float* u_inout)
   memcpy(u_inout + 2 * T, c->h_out + 2 * T, T * sizeof(float));
 }
 
+// the pass's echo of the tick block's number (SmpcDev::canary): anything but this tick's number
+// means the kernels did not read the block the host handed over
+static int check_canary(smpc_ctx* c)
+{
+  c->launched = false;
+  if (!c->canary_expect) return SMPC_OK;
+  const uint32_t got = reinterpret_cast<const volatile uint32_t*>(c->h_out)[3 * c->cfg.time_steps + 5];
+  if (got == c->canary_expect) return SMPC_OK;
+  char msg[200];
+  snprintf(msg, sizeof(msg), "the scoring pass read tick block %u, not %u: the per-tick upload did not reach the "
+           "device in time (CPU stores through the BAR: %s); SMPC_NO_BAR_TICK=1 selects the copy", got, c->canary_expect,
+           c->bar_tick ? "on" : "off");
+  c->bar_tick = false;   // later ticks of this ctx take the copy
+  return fail(c, SMPC_ERR_DEVICE, msg);
+}
+
 int fetch_out(smpc_ctx* c)
 {
   // The finishing kernel wrote u and the result into host-mapped memory and then the
@@ -223,13 +299,13 @@ int fetch_out(smpc_ctx* c)
         // smpc_grid_tail's mark: a reducing block gave up waiting for the grid's other blocks
         if (c->h_out[3 * c->cfg.time_steps + 6] == 2.0f)
           return fail(c, SMPC_ERR_DEVICE, "the scoring launch's reduction did not see every block's partial");
-        return SMPC_OK;
+        return check_canary(c);
       }
       __builtin_ia32_pause();
     }
   }
   HIPCK(c, hipStreamSynchronize(c->stream));
-  return SMPC_OK;
+  return check_canary(c);
 }
 
 float profile_pass_ms(smpc_ctx* c)
@@ -421,6 +497,12 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, dev));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) large_bar = 0;
+    c->bar_tick = large_bar != 0 && getenv("SMPC_NO_BAR_TICK") == nullptr;
+    if (c->bar_tick && !getenv("SMPC_NO_HDP_FLUSH")) c->hdp_flush = find_hdp_flush(dev);
+  }
   CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   c->poll_enabled = getenv("SMPC_NO_POLL") == nullptr;
@@ -481,7 +563,8 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipHostMalloc(&c->h_lut_fp, 512 * sizeof(SmpcLut), hipHostMallocDefault));
   CK(hipHostMalloc(&c->h_lut, 256 * sizeof(SmpcLut), hipHostMallocDefault));
   const size_t TL = 4 + 3 * static_cast<size_t>(T);
-  CK(hipMalloc(&c->d_partials, kMaxGrid * TL * sizeof(float)));
+  CK(hipMalloc(&c->d_partials, (kMaxGrid * TL + 16) * sizeof(float)));   // + the canary's slot (SMPC_CANARY_SLOT)
+  CK(hipMemset(c->d_partials, 0, (kMaxGrid * TL + 16) * sizeof(float)));
   CK(hipMalloc(&c->d_tuple, TL * sizeof(float)));
   CK(hipMalloc(&c->d_out, (3 * T + 8) * sizeof(float)));
   // [3T + 8 ...]: completion words, one per publishing block (at most 13: T = 128)

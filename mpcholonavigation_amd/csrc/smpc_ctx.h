@@ -92,7 +92,7 @@ inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
 constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
 constexpr uint32_t kLaneMaxT = 128;       // T <= 64: 3 x 64 noised controls parked per lane (or re-read); T <= 128: re-read
 constexpr uint32_t kPollWords = 32;     // completion words behind h_out[3T + 8] (T = 256: 25 blocks of smpc_reduce_partials)
-constexpr uint32_t kMaxGrid = 2048;       // smpc_reduce_partials stages this many factors
+constexpr uint32_t kMaxGrid = SMPC_MAX_GRID;   // smpc_reduce_partials stages this many factors
 constexpr uint32_t kWindowBytes = 96 * 96;  // costmap window staged in LDS: 4.8 m x 4.8 m at
                                            // 0.05 m around the robot; the rest is read from HBM/L2
 constexpr uint32_t kWindowSideMax = 144;       // T > 64: up to 144 x 144 cells (20 KB, +-3.6 m at 0.05 m: measured optimum, smpc_prepare.cpp)
@@ -208,6 +208,15 @@ struct smpc_ctx {
   uint8_t* d_tick = nullptr;
   uint8_t* h_tick = nullptr;  // pinned
   size_t tick_cap = 0;
+  // The per-tick upload as CPU stores straight into device memory (large-BAR systems: every
+  // MI355X host maps the whole HBM) instead of a copy on the stream: no blit kernel (3.4 us) and
+  // no dependent-dispatch gap (4 us) in front of the scoring pass.  SMPC_NO_BAR_TICK=1: the copy.
+  bool bar_tick = false;
+  volatile uint32_t* hdp_flush = nullptr;   // HDP_MEM_FLUSH_CNTL of this device, or null
+  size_t tick_used = 0;         // bytes of the tick block this tick fills (a multiple of 16)
+  uint32_t tick_no = 0;         // number of the tick block last handed over (its canary word)
+  uint32_t canary_expect = 0;   // != 0: fetch_out checks the pass's echo against it
+  bool launched = false;        // kernels of this ctx may still be reading the tick block
   // reductions / outputs
   float* d_partials = nullptr;
   float* d_tuple = nullptr;
@@ -284,11 +293,17 @@ int fail(smpc_ctx* c, int code, const std::string& msg);
   } while (0)
 
 int wait_map_upload(smpc_ctx* c);
+// n bytes (a multiple of 16, both 16-byte aligned) from pinned host memory into BAR-mapped device
+// memory: streaming stores, fenced before the caller rings any doorbell
+void bar_copy(void* dev_dst, const void* host_src, size_t n);
+// ... and the device's host-data-path flush behind them (HSA_AMD_AGENT_INFO_HDP_FLUSH), where the
+// runtime exposes one
+void bar_flush(const smpc_ctx* c);
 void free_ctx(smpc_ctx* c);
 
 // tick block layout (offsets in bytes), sized for the ctx's T and SMPC_MAX_PATH
 struct TickLayout {
-  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, pang_active, lut_cost, total;
+  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, pang_active, lut_cost, canary, total;
 };
 TickLayout tick_layout(uint32_t T, uint32_t P);
 

@@ -149,6 +149,12 @@ struct SmpcDev {
   SmpcFinal fin;            // single-GPU tick: finish the control sequence and publish it to the host
   // developer aid (SMPC_LANE_TIMELINE=1): [gridDim.x][8] shader-clock stamps of the lane pass
   unsigned long long* timeline;
+  // The tick block reaches device memory by CPU stores through the PCIe BAR (smpc_prepare.cpp).
+  // Its first word, four floats in front of u, is the tick's number; block 0 of a scoring pass
+  // leaves the value IT read behind the grid's partials (SMPC_CANARY_SLOT), the reduction hands
+  // it to the host with the result, and the host refuses a tick whose pass read another tick's
+  // block.  (0: u is not in the tick block — kernel arguments, pinned host memory.)
+  uint32_t canary_echo;
   // The tick block INSIDE the kernel arguments (small ticks: T <= 64, P <= 64).  The per-tick
   // upload is ~2 KB that the whole grid needs before its first instruction; as a separate
   // host-to-device copy it costs a blit kernel (3.4 us) and the dependency gap behind it
@@ -165,6 +171,8 @@ struct SmpcDev {
   float u_arg[3 * 64] __attribute__((aligned(16)));
 };
 #define SMPC_INLINE_TICK_CAP 1536u
+#define SMPC_MAX_GRID 2048u                                /* blocks of a pass (partials the reduction stages) */
+#define SMPC_CANARY_SLOT(T) (SMPC_MAX_GRID * (4u + 3u * (T)))   /* float index into SmpcDev::partials */
 #define SMPC_TAIL_MAX_GRID 512u
 #define SMPC_TAIL_STAMPS_AT (8192u + 2048u * 8u)   /* behind the lane pass's stamps in SmpcDev::timeline */
 // LDS floats smpc_grid_tail works in (from offset 0 of the launch's dynamic LDS, which the pass

@@ -169,7 +169,15 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     c->passes++;
     c->last_pass_kind = 1;
   }
-  HIPCK(c0, hipMemcpyAsync(g->d_all, g->h_all, g->total, hipMemcpyHostToDevice, g->stream));
+  // one hand-over for every member's tick block and parameter block: CPU stores through the BAR
+  // (every member's last tick was fetched: nothing reads the buffer), else a copy on the stream
+  if (c0->bar_tick) {
+    // (only what this tick wrote: a slot is sized for the longest path, 25 KB, a tick fills ~4)
+    for (uint32_t i = 0; i < n; ++i) bar_copy(g->d_all + g->slot * i, g->h_all + g->slot * i, g->ctxs[i]->tick_used);
+    bar_copy(g->d_all + g->off_dev, g->h_all + g->off_dev, g->total - g->off_dev);
+    bar_flush(c0);
+  }
+  else HIPCK(c0, hipMemcpyAsync(g->d_all, g->h_all, g->total, hipMemcpyHostToDevice, g->stream));
   HIPCK(c0, smpc_launch_pass_lane_many(reinterpret_cast<const SmpcDev*>(g->d_all + g->off_dev), n,
                                        T == 64, obst, dep, T, L, gridx, c0->lane_block, g->stream));
   HIPCK(c0, smpc_launch_reduce_many(reinterpret_cast<const SmpcReduceArgs*>(g->d_all + g->off_red), n,

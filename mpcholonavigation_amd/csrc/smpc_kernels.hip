@@ -284,6 +284,10 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   float* ring_x = scr + L.scr_ring;      // [64] parked rollout endpoints
   float* ring_y = ring_x + WAVE;
   float* cring = scr + L.scr_c;          // [group][3][T] parked noised controls
+  // which tick block this launch reads (SmpcDev::canary_echo): its number sits four floats in
+  // front of u; left behind the partials for the reduction to hand to the host
+  if (!FURTHEST_ONLY && p.canary_echo && !(p.flags & SD_ACCUMULATE) && blockIdx.x == 0 && tid == 0)
+    p.partials[SMPC_CANARY_SLOT(p.T)] = p.u[-4];
 
   // ---- stage costmap window, LUT and path into LDS -------------------------
   if (!FURTHEST_ONLY && (p.flags & (SD_OBSTACLES | SD_COST))) {
@@ -1219,6 +1223,13 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
         }
       }
     }
+    // the tick block's number as the pass read it (SMPC_CANARY_SLOT): to the device copy of the
+    // result (the combine kernels forward it from there) and, when finishing, to the host
+    if (col == 0 && fin.u_dev) {
+      const float cn = partials[SMPC_CANARY_SLOT(T)];
+      fin.u_dev[3 * T + 5] = cn;
+      if (fin.enabled && fin.u_host) fin.u_host[3 * T + 5] = cn;
+    }
   }
   // completion for the polling host: every block publishes the tick's sequence number in its
   // own word (u_host[3T + 8 + block]) behind a system-scope fence over its host stores, and the
@@ -1293,6 +1304,7 @@ __device__ __forceinline__ void combine_tuples_body(const float* __restrict__ tu
       result[k] = res[k];
       if (host_out) host_out[3 * T + k] = res[k];
     }
+    if (host_out) host_out[3 * T + 5] = result[5];   // the pass's echo of the tick block's number (smpc_reduce_partials)
   }
   // completion word for the polling host, behind every host store of this (single) block
   if (host_out && seq) {
@@ -1607,7 +1619,7 @@ hipError_t smpc_launch_reduce(const float* partials, uint32_t nblk, uint32_t T,
 __global__ void __launch_bounds__(1024) smpc_publish_many(const SmpcReduceArgs* __restrict__ many,
                                                          uint32_t n, uint32_t T)
 {
-  const uint32_t len = 3 * T + 5;
+  const uint32_t len = 3 * T + 6;   // u, the five results, the tick block's number
   for (uint32_t i = threadIdx.x; i < n * len; i += blockDim.x) {
     const uint32_t q = i / len, k = i - q * len;
     many[q].host_out[k] = many[q].fin.u_dev[k];

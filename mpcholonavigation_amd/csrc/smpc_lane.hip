@@ -1077,6 +1077,12 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     smpc_store_partial(outp + i, acc);
   }
   stamp(6);
+  // Which tick block this launch read (SmpcDev::canary_echo): its number sits four floats in front
+  // of u; block 0 leaves it behind the grid's partials for the reduction to hand to the host.
+  // Unconditional wherever u is the tick block's own (the host knows when the word means nothing)
+  // and through the two pointers the kernel holds anyway: a pointer or a flag of its own, live
+  // across the time loop, cost the T = 64 instance 20 bytes of scratch.
+  if (!(p.flags & SD_ACCUMULATE) && blockIdx.x == 0 && tid == 0) outp[SMPC_CANARY_SLOT(T)] = cu[-4];
   if constexpr (!MANY && !RR) {   // (the re-read form's grid is three blocks per CU: over SMPC_TAIL_MAX_GRID)
     if (p.tail) smpc_grid_tail<(RR ? LANE_BLOCK_RR : LANE_BLOCK) / 64>(p, smem);   // (the host: full-size blocks only)
   }

@@ -10,6 +10,9 @@ TickLayout tick_layout(uint32_t T, uint32_t P)
 {
   TickLayout l{};
   size_t o = 0;
+  // the tick's number sits right in front of u: a pass finds it at u[-4] with no pointer of its
+  // own (the lane pass has no scalar register to spare for one)
+  l.canary = o; o += 16;
   l.u = o; o += align_up(3 * T * 4, 16);
   l.px = o; o += align_up(P * 4, 16);
   l.py = o; o += align_up(P * 4, 16);
@@ -707,7 +710,24 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   // not the default: every block of the grid fetches its ~2 KB across PCIe, uncached.
   const bool pinned_tick = c->knob_pinned_tick && !c->defer_upload && !inline_tick;
   const uint8_t* const tb = pinned_tick ? h : c->d_tick;
-  if (!c->defer_upload && !pinned_tick) {
+  // the tick block's number: written last, echoed by block 0 of every pass that reads the block
+  // from device memory (SmpcDev::canary)
+  if (++c->tick_no == 0) ++c->tick_no;
+  *reinterpret_cast<uint32_t*>(h + tl.canary) = c->tick_no;
+  c->tick_used = tl.total;
+  const bool bar = c->bar_tick && !c->defer_upload && !pinned_tick && !inline_tick;
+  // (whoever uploads: this ctx or its group; the in-launch reduction experiment does not carry it)
+  c->canary_expect = (!pinned_tick && !inline_tick && !c->fused_reduce) ? c->tick_no : 0u;
+  if (bar) {
+    // no kernel of an earlier tick may still read the block (every tick ends with fetch_out;
+    // a tick abandoned on an error does not)
+    if (c->launched) {
+      HIPCK(c, hipStreamSynchronize(c->stream));
+      c->launched = false;
+    }
+    bar_copy(c->d_tick, h, tl.total);
+    bar_flush(c);
+  } else if (!c->defer_upload && !pinned_tick) {
     if (!inline_tick)
       HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));
     else if (gates & SD_COST)
@@ -818,6 +838,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.neg_inv_temp = -1 / c->cfg.temperature;
   d.k2 = d.neg_inv_temp * 1.4426950408889634f;
   d.timeline = c->d_timeline;
+  d.canary_echo = c->canary_expect ? 1u : 0u;
   if (inline_tick) memcpy(d.u_arg, h + tl.u, 3 * T * sizeof(float));
   if (inline_tick) {
     d.tick_inline = 1;

@@ -119,14 +119,37 @@ def test_all_collide_on_the_reread_form(Smpc, Oracle, iterations):
     """T = 128 on the lane pass's re-read form, which has instances with a collision critic
     scored only: the retry after fallback() (fail_flag_in: nothing is scored,
     critic_manager.cpp:70-73) and the later iterations of an all-collide tick (flags stripped the
-    same way) must run — on the wave pass — not fail with a device error."""
+    same way) must run — on the wave pass — not fail with a device error.
+
+    What can be asserted about the numbers: with every rollout colliding the costs are
+    critical_weight x collision_cost = 2e5 each, where a float's ulp is 0.0156 — 5 % of a softmax
+    weight at temperature 0.3.  The first iteration adds ONE rounded sum to zero and matches the
+    oracle as everywhere else; from the second on the reference adds its three gamma terms to the
+    accumulated 2e5 one by one (optimizer.cpp:365-380), the kernels add their sum once, the costs
+    differ by an ulp and the weights by percents.  The reference is no better conditioned against
+    itself (-ffast-math may reassociate the same adds), and no Twist comes out of such a tick:
+    fail_flag is never cleared inside evalControl, so fallback() resets and finally throws
+    (optimizer.cpp:134-183).  Hence: integer outputs exact, costs within two ulp, the control
+    sequence within the weights' conditioning."""
     cfg, scn, noise = make_case(1024, 128, all_lethal=True)
     cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
     cfg.iteration_count = iterations
     g, o, (ug, og), (uo, oo) = run_pair(Smpc, Oracle, cfg, scn, noise)
     assert og.fail_flag == 1 and oo.fail_flag == 1
     assert og.non_colliding == 0
-    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=f"all collide T=128 it={iterations}")
+    assert og.passes == iterations + 1      # the all-collide re-score of the first iteration
+
+    def check(ug, og, uo, oo, label):
+        if iterations == 1:
+            assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), label=label)
+            return
+        cg, co = g.get_costs(), o.get_costs()
+        ulp = float(np.spacing(np.float32(np.max(np.abs(co)))))
+        assert float(np.max(np.abs(cg.astype(np.float64) - co))) <= max(2 * ulp, 2e-4), label
+        assert og.fail_flag == oo.fail_flag and og.non_colliding == oo.non_colliding
+        assert rel_err(ug, uo) < 5e-2, label
+
+    check(ug, og, uo, oo, f"all collide T=128 it={iterations}")
     t = scn.tick
     t2 = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw, t.goal_x,
               t.goal_y, fail_flag_in=True)
@@ -134,7 +157,8 @@ def test_all_collide_on_the_reread_form(Smpc, Oracle, iterations):
     ug2, og2 = g.optimize(t2, u0)
     uo2, oo2 = o.optimize(t2, u0)
     assert og2.fail_flag == 1 and oo2.fail_flag == 1
-    assert_parity(ug2, og2, uo2, oo2, g.get_costs(), o.get_costs(), label=f"sticky fail T=128 it={iterations}")
+    assert og2.pass_kind == 0               # nothing to score: the wave pass
+    check(ug2, og2, uo2, oo2, f"sticky fail T=128 it={iterations}")
 
 
 def test_two_iterations_accumulate_costs(Smpc, Oracle, both_passes):
