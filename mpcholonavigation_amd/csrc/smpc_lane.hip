@@ -52,6 +52,9 @@
 #define LANE_X_GAMMA_N 0     // gamma terms from the noise itself instead of c - u (measured: the noise
                              // registers' longer life breaks the four-step prefetch, +35 % at 2 M rollouts)
 #endif
+#ifndef LANE_X_GAMMA_UC
+#define LANE_X_GAMMA_UC 1    // gamma terms as sum u c - sum u^2 (one fma per control and step; the constant from LDS)
+#endif
 #ifndef LANE_X_PFW_MIN
 #define LANE_X_PFW_MIN 1     // PreferForward as -dt sum min(vx, 0)
 #endif
@@ -295,6 +298,9 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   float* s_D = reinterpret_cast<float*>(smem + L.off_D) + 1;
   // PathAlign's view of the path: {x, y, segment valid ? 1 : 0, 0} per point, one 16-byte read
   f32x4* s_pts4 = reinterpret_cast<f32x4*>(smem + L.off_pts4);
+  // sum_t u[ctrl][t]^2 of this launch's control sequence, ctrl = vx, vy, wz (the gamma terms):
+  // the 16 bytes in front of the per-wave scratch (smpc_prepare.cpp lane_lds)
+  float* s_su2 = reinterpret_cast<float*>(smem + L.off_scr) - 4;
 
   constexpr int BLK = RR ? LANE_BLOCK_RR : LANE_BLOCK;   // the largest block; small batches launch half of it
   const int blk = blockDim.x;
@@ -365,6 +371,28 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       if (seg_on) s_D[tid] = g_D;
       s_pts4[tid] = f32x4{g_px, g_py, g_valid ? 1.0f : 0.f, 0.f};
     }
+#if LANE_X_GAMMA_UC
+    if (tid < WAVE) {   // (one wave: lane t squares u[.][t], then a butterfly)
+      float a = 0.f, b = 0.f, c = 0.f;
+      const uint32_t Tn = FULL ? 64u * NCH : (TC ? (uint32_t)TC : p.T);
+      for (uint32_t t = (uint32_t)tid; t < Tn; t += WAVE) {
+        const float ux = tk.u[t], uy = tk.u[Tn + t], uz = tk.u[2 * Tn + t];
+        a = fmaf(ux, ux, a);
+        b = fmaf(uy, uy, b);
+        c = fmaf(uz, uz, c);
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, WAVE);
+        b += __shfl_xor(b, o, WAVE);
+        c += __shfl_xor(c, o, WAVE);
+      }
+      if (tid == 0) {
+        s_su2[0] = a;
+        s_su2[1] = b;
+        s_su2[2] = c;
+      }
+    }
+#endif
     for (uint32_t i = tid + blk; i < p.P; i += blk) {   // paths beyond one point per thread
       const float qx = tk.px[i], qy = tk.py[i];
       const bool seg = i + 1 < p.P;
@@ -624,7 +652,15 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       // updateControlSequence gamma terms (optimizer.cpp:365-380): sum_t u (c - u).  c - u is
       // the noise up to the rounding of c = u + n (|c - u - n| <= ulp(c) / 2: a few 1e-8 on
       // terms that gamma / sigma^2 scales to ~1e-7 of a cost): the noise itself is used
-#if LANE_X_GAMMA_N
+#if LANE_X_GAMMA_UC
+      // ... as sum_t u c - sum_t u^2: one fused multiply-add per control here, the constant
+      // (s_su2, formed once per launch) subtracted once per rollout.  Half the instructions of
+      // u (c - u); the running sums reach T |u| |c| instead of staying near zero, which is ~1e-6
+      // absolute on a cost after the gamma / sigma^2 scaling (costs are compared at 2e-4).
+      gx = fmaf(ux, cvx, gx);
+      gz = fmaf(uz, cwz, gz);
+      gy = fmaf(uy, cvy, gy);
+#elif LANE_X_GAMMA_N
       gx = fmaf(ux, n0, gx);
       gz = fmaf(uz, n2, gz);
       gy = fmaf(uy, n1, gy);
@@ -936,9 +972,15 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     if (p.flags & SD_PREFER_FORWARD) lin += pfw * p.pfw_weight;
 #endif
     if (ga_on) uni += (ga_sum / (float)T) * p.ga_weight;
+#if LANE_X_GAMMA_UC
+    lin += p.g_vx * (gx - s_su2[0]);
+    lin += p.g_wz * (gz - s_su2[2]);
+    lin += p.g_vy * (gy - s_su2[1]);
+#else
     lin += p.g_vx * gx;
     lin += p.g_wz * gz;
     lin += p.g_vy * gy;
+#endif
     cost += uni + lin;
     if (pa_on) {
       const float c_pa = pa_num > 0.f ? pa_sum * fast_rcp(pa_num) : 0.f;

@@ -67,7 +67,7 @@ SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T, bool rr)
   SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64,
                         window_bytes != 0, 0);
   Lt.off_pts4 = Lt.off_scr;
-  Lt.off_scr += align_up(std::max(P, 1u) * 16, 16);
+  Lt.off_scr += align_up(std::max(P, 1u) * 16, 16) + 16;   // + sum u^2 per control (the gamma terms), 16 bytes
   Lt.scr_stride = rr ? align_up(4u + 3u * T, 4) : align_up(std::max(64u * 68u + 64u, 4u + 3u * T), 4);
   Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
   return Lt;
