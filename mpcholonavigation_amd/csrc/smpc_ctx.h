@@ -65,6 +65,8 @@ hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool fu
                                       const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
                                    float neg_inv_temp, hipStream_t st);
+// developer aid: the scoring-pass instance launched last by this thread, as rocprofv3 names it
+extern thread_local char smpc_last_pass_kernel[96];
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
 
 namespace smpc_impl {

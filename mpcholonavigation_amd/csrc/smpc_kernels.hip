@@ -19,6 +19,7 @@
 // reference's separate xtensor passes.
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <algorithm>
 #include <stdint.h>
 
@@ -1541,10 +1542,13 @@ hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, 
 // ---------------------------------------------------------------------------
 // launch wrappers (called from smpc_api.cpp through plain C++ linkage)
 // ---------------------------------------------------------------------------
+thread_local char smpc_last_pass_kernel[96] = "";
+
 template <int MODE, bool FULL>
 static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint32_t grid,
                                 uint32_t block, hipStream_t st)
 {
+  snprintf(smpc_last_pass_kernel, sizeof(smpc_last_pass_kernel), "smpc_pass<%d, %d, %s>", R, MODE, FULL ? "true" : "false");
   switch (R) {
     case 1: hipLaunchKernelGGL((smpc_pass<1, MODE, FULL>), dim3(grid), dim3(block), L.total, st, p, L); break;
     case 2: hipLaunchKernelGGL((smpc_pass<2, MODE, FULL>), dim3(grid), dim3(block), L.total, st, p, L); break;

@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <type_traits>
 
@@ -1130,6 +1131,15 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   }
 }
 
+extern thread_local char smpc_last_pass_kernel[96];   // smpc_kernels.hip
+// the instance's name with every template argument written out, as rocprofv3 prints it
+static void lane_name(bool full, bool obst, bool many, int nch, bool rr, bool ga, bool quads, int tc, bool dep)
+{
+  auto b = [](bool v) {return v ? "true" : "false";};
+  snprintf(smpc_last_pass_kernel, sizeof(smpc_last_pass_kernel), "smpc_pass_lane<%s, %s, %s, %d, %s, %s, %s, %d, %s>", b(full),
+           b(obst), b(many), nch, b(rr), b(ga), b(quads), tc, b(dep));
+}
+
 // rr: the re-read instances (no parked controls; required for T > 64; ObstaclesCritic scored)
 // block: threads per block of the parking form — LANE_BLOCK, or LANE_BLOCK / 2 for batches of at
 // most one group per SIMD (a wave alone on its SIMD runs a group in 2/3 of the time)
@@ -1147,6 +1157,7 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
     if (p.T > 64u) SMPC_LANE_LAUNCH_RR(2);
     else SMPC_LANE_LAUNCH_RR(1);
 #undef SMPC_LANE_LAUNCH_RR
+    lane_name(true, true, false, p.T > 64u ? 2 : 1, true, false, true, 0, false);
     return hipGetLastError();
   }
   const bool full = p.T == 64u;
@@ -1160,6 +1171,7 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
     else
       hipLaunchKernelGGL((smpc_pass_lane<false, true, false, 1, false, false, true, 56, true>), dim3(grid), dim3(block), L.total,
                          st, p, L, static_cast<const SmpcDev*>(nullptr));
+    lane_name(full, true, false, 1, false, false, true, full ? 0 : 56, true);
     return hipGetLastError();
   }
   if (p.flags & SD_GOAL_ANGLE) {   // near-goal tick: the instances with the GoalAngle term
@@ -1170,11 +1182,16 @@ hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t gr
     if (full) SMPC_LANE_LAUNCH_GA(true);
     else SMPC_LANE_LAUNCH_GA(false);
 #undef SMPC_LANE_LAUNCH_GA
+    lane_name(full, true, false, 1, false, true, full, 0, false);
     return hipGetLastError();
   }
 #define SMPC_LANE_LAUNCH(F, O) \
   hipLaunchKernelGGL((smpc_pass_lane<F, O, false, 1, false>), dim3(grid), dim3(block), L.total, st, p, L, \
                      static_cast<const SmpcDev*>(nullptr))
+  if (full) lane_name(true, obst, false, 1, false, false, true, 0, false);
+  else if (obst && p.T == 56u) lane_name(false, true, false, 1, false, false, true, 56, false);
+  else if (obst && (p.T & 3u) == 0u) lane_name(false, true, false, 1, false, false, true, 0, false);
+  else lane_name(false, obst, false, 1, false, false, false, 0, false);
   if (full && obst) SMPC_LANE_LAUNCH(true, true);
   else if (full) SMPC_LANE_LAUNCH(true, false);
   else if (obst && p.T == 56u)         // the reference's default horizon, at compile time
@@ -1198,6 +1215,8 @@ hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool fu
 {
   if (block != LANE_BLOCK && block != LANE_BLOCK / 2) return hipErrorInvalidValue;
   const SmpcDev none{};
+  if (dep) lane_name(full, true, true, 1, false, false, true, full ? 0 : 56, true);
+  else lane_name(full, obst, true, 1, false, false, full, 0, false);
   if (dep) {
     if (!obst || (!full && T != 56u)) return hipErrorInvalidValue;
     if (full)

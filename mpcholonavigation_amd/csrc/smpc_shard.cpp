@@ -9,7 +9,15 @@ const RcclApi* rccl()
 {
   static const RcclApi* api = []() -> const RcclApi* {
     void* h = nullptr;
+    // SMPC_RCCL_LIB: the library to take the six nccl* entry points from instead of librccl.so
+    // (tests/fake_rccl: the world > 1 control flow with several processes on one GPU, which RCCL
+    // refuses).  Read once per process; no fall-through when it is set and cannot be loaded.
+    if (const char* over = getenv("SMPC_RCCL_LIB")) {
+      h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!h) return nullptr;
+    }
     for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      if (h) break;
       h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);   // the copy the process already has
       if (h) break;
     }

@@ -320,6 +320,122 @@ def _report(res):
     return "\n".join(f"---- rank {r}: rc={res[r][0]} ----\n{res[r][1][-2500:]}" for r in order)
 
 
+_FAKE_RCCL_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SMPC_REPO"])
+from mpcholonavigation_amd.optimizer import Smpc
+from mpcholonavigation_amd.tick import Tick, default_config
+from tests.helpers import configure, make_case
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, T = 8192, 40
+per = B // world
+a, b = rank * per, (rank + 1) * per
+
+
+def build(all_lethal):
+    cfg, scn, noise = make_case(B, T, all_lethal=all_lethal)
+    ref = None
+    if rank == 0:
+        ref = Smpc(cfg)
+        configure(ref, scn, noise=noise)
+    sh = Smpc(default_config(batch_size=per, time_steps=T, shard_offset=a, global_batch_size=B))
+    configure(sh, scn, noise=tuple(n[a:b] for n in noise))
+    ids = [sh.shard_comm_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    sh.shard_comm_init(ids[0], rank, world)
+    return scn, ref, sh
+
+
+def tick_all(sh, ref, tk, u, speculate, label):
+    err, us, outs = None, None, None
+    try:
+        us, outs = sh.shard_tick(tk, u, speculate)
+    except Exception as e:
+        err = f"{label}: {e!r}"
+        print(f"FAKE_RCCL_FAIL rank {rank} {err}", flush=True)
+    got = [None] * world
+    dist.all_gather_object(got, (err, None if us is None else us.tobytes(),
+                                 None if outs is None else (outs.fail_flag, outs.furthest_reached_path_point,
+                                                            outs.non_colliding, outs.passes)))
+    if any(g[0] for g in got):
+        print(f"FAKE_RCCL_ABORT rank {rank}: {[g[0] for g in got]}", flush=True)
+        sys.exit(3)
+    assert all(g[1] == got[0][1] and g[2] == got[0][2] for g in got), f"{label}: ranks disagree {[g[2] for g in got]}"
+    if rank == 0:
+        ur, outr = ref.optimize(tk, u)
+        assert outs.fail_flag == outr.fail_flag, label
+        assert outs.furthest_reached_path_point == outr.furthest_reached_path_point, label
+        assert outs.non_colliding == outr.non_colliding, label
+        np.testing.assert_allclose(us, ur, rtol=2e-5, atol=2e-6, err_msg=label)
+    return us, outs
+
+
+def shifted(u):
+    return np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+
+
+# 1. speculating closed loop: the first tick has no prediction (furthest-only pass + the MAX
+# exchange), tick 3 jumps the pose so that every rank misses the same speculation and re-scores
+scn, ref, sh = build(False)
+dist.barrier()
+t = scn.tick
+u = scn.u0
+passes = []
+for k in range(6):
+    dx = 0.02 * k + (0.6 if k >= 3 else 0.0)
+    tk = Tick(t.pose_x + dx, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw, t.goal_x, t.goal_y)
+    us, outs = tick_all(sh, ref, tk, u, True, f"speculating tick {k}")
+    passes.append(int(outs.passes))
+    u = shifted(us)
+print(f"FAKE_RCCL_PASSES rank {rank} {passes}", flush=True)
+assert passes[0] == 1, passes            # no prediction yet: furthest-only pass, MAX exchange, ONE scoring pass
+assert passes[3] == 2, passes            # the jump: speculation miss, agreed on by both ranks, re-scored
+assert 1 in passes[1:], passes           # ... and speculation hits
+# 2. not speculating: the MAX exchange in front of every scoring pass
+u = scn.u0
+for k in range(2):
+    us, outs = tick_all(sh, ref, t, u, False, f"two-pass tick {k}")
+    assert outs.passes == 1              # (scoring passes: the furthest-only pass in front is not counted)
+    u = shifted(us)
+sh.close()
+# 3. every rollout of the WHOLE batch collides: the shards learn it from the gathered tuples and
+# re-score with the collision critic only (critic_manager.cpp:70-73), all of them
+scn, ref, sh = build(True)
+dist.barrier()
+us, outs = tick_all(sh, ref, scn.tick, scn.u0, True, "all collide")
+assert outs.fail_flag == 1 and outs.non_colliding == 0
+dist.barrier()
+print("FAKE_RCCL_OK", rank, flush=True)
+"""
+
+
+def test_shard_tick_world2_control_flow_with_a_stand_in_for_rccl(tmp_path):
+    """smpc_shard_tick — the DEFAULT exchange at N > 1: ncclAllGather of the shard tuples, plus
+    ncclAllReduce(MAX) when not speculating — with TWO ranks as processes on this one GPU.  RCCL
+    refuses two ranks on one device, so the six nccl* symbols libsmpc resolves come from
+    tests/fake_rccl (host-staged over shared memory) through SMPC_RCCL_LIB.  Covered: the first
+    tick's furthest-only pass + MAX exchange, speculation hits, a speculation miss both ranks
+    agree on and re-score, the non-speculating mode, the all-collide re-score; every tick equal
+    on both ranks and equal to the unsharded tick.
+
+    What it cannot prove: anything about RCCL itself (stream-ordered collectives, its kernels),
+    xGMI, or timing — the stand-in drains the stream and stages through host memory."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-s", "-C", os.path.join(here, "fake_rccl")], check=True)
+    res = _run_ranks(tmp_path, _FAKE_RCCL_WORKER, 2, 29631, extra_env={"SMPC_RCCL_LIB": lib}, timeout=300)
+    ok = all(rc == 0 and "FAKE_RCCL_OK" in o for rc, o in res)
+    assert ok, _report(res)
+    print("\n".join(l for _, o in res for l in o.splitlines() if "FAKE_RCCL_PASSES" in l))
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_mailbox_tick_processes_on_one_gpu(tmp_path, world):
     """Two and four ranks as PROCESSES SHARING THIS GPU exchange their shard tuples through
