@@ -380,6 +380,14 @@ int smpc_seed(smpc_ctx* ctx, uint64_t seed);
  * [ref src/noise_generator.cpp:54-63,97-105]: draw the next epoch's noise now
  * (device-RNG mode only; constraints and costs are left alone). */
 int smpc_redraw_noise(smpc_ctx* ctx);
+/* The same draw OFF the tick's critical path, as the reference runs it (a thread draws the next
+ * tensors while the optimizer goes on, noise_generator.cpp:54-63,97-105): the next epoch is drawn
+ * into a second set of tensors on a stream of its own and the call returns at once; the next
+ * tick (smpc_optimize, smpc_shard_begin / _tick, smpc_group_optimize) waits for the draw on the
+ * device and scores with it.  A second call before a tick has taken the first draw is a no-op;
+ * smpc_seed / smpc_reset / smpc_set_noise / smpc_redraw_noise drop a draw not yet taken.  Doubles
+ * the noise tensors' memory (allocated at the first call). */
+int smpc_redraw_noise_async(smpc_ctx* ctx);
 
 /* Copy the ctx's noise tensors back (tests / RNG parity). Any pointer may be NULL. */
 int smpc_get_noise(smpc_ctx* ctx, float* noise_vx, float* noise_vy, float* noise_wz);

@@ -254,6 +254,7 @@ PROTOTYPES = {
     "smpc_set_noise": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smpc_seed": (C.c_int, [_ctx, C.c_uint64]),
     "smpc_redraw_noise": (C.c_int, [_ctx]),
+    "smpc_redraw_noise_async": (C.c_int, [_ctx]),
     "smpc_get_noise": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smpc_optimize": (C.c_int, [_ctx, C.POINTER(SmpcTickIn), C.c_void_p,
                                 C.POINTER(SmpcTickOut)]),

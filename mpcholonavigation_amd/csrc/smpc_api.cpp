@@ -96,6 +96,13 @@ void free_ctx(smpc_ctx* c)
   for (float* p : {c->d_tvx, c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
          c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
     if (p) (void)hipFree(p);
+  if (c->fill_stream) {
+    (void)hipStreamSynchronize(c->fill_stream);
+    (void)hipStreamDestroy(c->fill_stream);
+  }
+  if (c->ev_fill) (void)hipEventDestroy(c->ev_fill);
+  for (float* p : {c->b_tvx, c->b_nvx, c->b_nvy, c->b_nwz})
+    if (p) (void)hipFree(p);
   if (c->d_map) (void)hipFree(c->d_map);
   if (c->d_timeline) (void)hipFree(c->d_timeline);
   if (c->map.cells) (void)hipHostFree(c->map.cells);
@@ -363,37 +370,112 @@ int ensure_row_major(smpc_ctx* c)
   return SMPC_OK;
 }
 
-int draw_noise(smpc_ctx* c)
+// One epoch of the device RNG into the given set of tensors, on stream st (no wait).
+// rm_valid_out: whether the [B,T] tensors of the set hold the draw (else only the time-major ones)
+static int launch_draw(smpc_ctx* c, float* nvx, float* nvy, float* nwz, float* tvx, float* tvy, float* twz,
+                       hipStream_t st, bool* rm_valid_out)
 {
   const uint64_t n = static_cast<uint64_t>(c->cfg.batch_size) * c->cfg.time_steps;
   const uint64_t base = c->cfg.shard_offset * c->cfg.time_steps;
-  if (c->use_tpr && (c->cfg.time_steps & 1u) == 0 && !getenv("SMPC_NO_FUSED_FILL")) {
+  const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
+  if (c->use_tpr && (T & 3u) == 0 && !getenv("SMPC_NO_FUSED_FILL")) {
     // lane-per-rollout contexts: draw straight into the time-major layout that pass reads —
     // one write of the noise instead of a write, a read and a second write (fill + transpose);
     // the [B,T] copy is made only if something asks for it (ensure_row_major)
-    const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
-    HIPCK(c, smpc_launch_fill_noise_tm(c->d_tvx, B, T, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
-    HIPCK(c, smpc_launch_fill_noise_tm(c->d_twz, B, T, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
+    HIPCK(c, smpc_launch_fill_noise_tm(tvx, B, T, base, c->seed, 0, c->epoch, c->cfg.vx_std, st));
+    HIPCK(c, smpc_launch_fill_noise_tm(twz, B, T, base, c->seed, 1, c->epoch, c->cfg.wz_std, st));
     if (c->holonomic)
-      HIPCK(c, smpc_launch_fill_noise_tm(c->d_tvy, B, T, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
+      HIPCK(c, smpc_launch_fill_noise_tm(tvy, B, T, base, c->seed, 2, c->epoch, c->cfg.vy_std, st));
     else
-      HIPCK(c, hipMemsetAsync(c->d_tvy, 0, n * sizeof(float), c->stream));
-    c->rm_valid = false;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    c->have_noise = true;
+      HIPCK(c, hipMemsetAsync(tvy, 0, n * sizeof(float), st));
+    *rm_valid_out = false;
     return SMPC_OK;
   }
   // draw order vx, wz, vy (noise_generator.cpp:107-122)
-  HIPCK(c, smpc_launch_fill_noise(c->d_nvx, n, base, c->seed, 0, c->epoch, c->cfg.vx_std, c->stream));
-  HIPCK(c, smpc_launch_fill_noise(c->d_nwz, n, base, c->seed, 1, c->epoch, c->cfg.wz_std, c->stream));
+  HIPCK(c, smpc_launch_fill_noise(nvx, n, base, c->seed, 0, c->epoch, c->cfg.vx_std, st));
+  HIPCK(c, smpc_launch_fill_noise(nwz, n, base, c->seed, 1, c->epoch, c->cfg.wz_std, st));
   // noises_vy_ keeps its zeros for a non-holonomic model (noise_generator.cpp:117-121)
-  if (c->holonomic)
-    HIPCK(c, smpc_launch_fill_noise(c->d_nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, c->stream));
-  int rc = update_time_major(c);
+  if (c->holonomic) HIPCK(c, smpc_launch_fill_noise(nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, st));
+  if (c->use_tpr) {
+    HIPCK(c, smpc_launch_transpose(nvx, tvx, B, T, st));
+    HIPCK(c, smpc_launch_transpose(nvy, tvy, B, T, st));
+    HIPCK(c, smpc_launch_transpose(nwz, twz, B, T, st));
+  }
+  *rm_valid_out = true;
+  return SMPC_OK;
+}
+
+// a draw requested with smpc_redraw_noise_async that no tick has taken yet is dropped (whoever
+// calls this is about to overwrite the noise anyway)
+int cancel_redraw(smpc_ctx* c)
+{
+  if (!c->redraw_pending) return SMPC_OK;
+  HIPCK(c, hipEventSynchronize(c->ev_fill));
+  c->redraw_pending = false;
+  return SMPC_OK;
+}
+
+// The tick about to be prepared takes the noise drawn in the background, if there is any: its
+// stream waits for the draw ON THE DEVICE and the two sets of tensors change places.
+int absorb_redraw(smpc_ctx* c)
+{
+  if (!c->redraw_pending) return SMPC_OK;
+  HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_fill, 0));
+  std::swap(c->d_nvx, c->b_nvx);
+  std::swap(c->d_nvy, c->b_nvy);
+  std::swap(c->d_nwz, c->b_nwz);
+  std::swap(c->d_tvx, c->b_tvx);
+  std::swap(c->d_tvy, c->b_tvy);
+  std::swap(c->d_twz, c->b_twz);
+  c->rm_valid = c->redraw_rm_valid;
+  c->redraw_pending = false;
+  c->noise_gen++;
+  return SMPC_OK;
+}
+
+int draw_noise(smpc_ctx* c)
+{
+  int rc = cancel_redraw(c);
+  if (rc != SMPC_OK) return rc;
+  bool rm = true;
+  rc = launch_draw(c, c->d_nvx, c->d_nvy, c->d_nwz, c->d_tvx, c->d_tvy, c->d_twz, c->stream, &rm);
   if (rc != SMPC_OK) return rc;
   HIPCK(c, hipStreamSynchronize(c->stream));
   c->have_noise = true;
-  c->rm_valid = true;
+  c->rm_valid = rm;
+  c->noise_gen++;
+  return SMPC_OK;
+}
+
+// NoiseGenerator::generateNextNoises as the reference runs it (noise_generator.cpp:54-63,97-105:
+// a thread draws the next tensors while the optimizer goes on): the next epoch goes into the
+// OTHER set of tensors on a stream of its own, and the call returns at once.
+int redraw_async(smpc_ctx* c)
+{
+  if (c->redraw_pending) return SMPC_OK;   // (the reference's signal is not counted either)
+  const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
+  if (!c->fill_stream) {
+    HIPCK(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_fill, hipEventDisableTiming));
+  }
+  if (c->use_tpr && !c->b_tvx) {
+    HIPCK(c, hipMalloc(&c->b_tvx, 3 * n));
+    c->b_tvy = c->b_tvx + n / sizeof(float);
+    c->b_twz = c->b_tvy + n / sizeof(float);
+  }
+  if (!c->b_nvx) {
+    HIPCK(c, hipMalloc(&c->b_nvx, n));
+    HIPCK(c, hipMalloc(&c->b_nvy, n));
+    HIPCK(c, hipMalloc(&c->b_nwz, n));
+    if (!c->holonomic) HIPCK(c, hipMemset(c->b_nvy, 0, n));
+  }
+  c->epoch++;
+  bool rm = true;
+  const int rc = launch_draw(c, c->b_nvx, c->b_nvy, c->b_nwz, c->b_tvx, c->b_tvy, c->b_twz, c->fill_stream, &rm);
+  if (rc != SMPC_OK) return rc;
+  HIPCK(c, hipEventRecord(c->ev_fill, c->fill_stream));
+  c->redraw_rm_valid = rm;
+  c->redraw_pending = true;
   return SMPC_OK;
 }
 }  // namespace smpc_impl
@@ -754,6 +836,10 @@ int smpc_set_noise(smpc_ctx* c, const float* nvx, const float* nvy, const float*
   if (!c || !nvx || !nvy || !nwz) return SMPC_ERR_INVALID;
   HIPCK(c, hipSetDevice(c->device));
   const size_t n = static_cast<size_t>(c->cfg.batch_size) * c->cfg.time_steps * sizeof(float);
+  {
+    const int rc = cancel_redraw(c);
+    if (rc != SMPC_OK) return rc;
+  }
   HIPCK(c, hipMemcpyAsync(c->d_nvx, nvx, n, hipMemcpyHostToDevice, c->stream));
   if (c->holonomic) HIPCK(c, hipMemcpyAsync(c->d_nvy, nvy, n, hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipMemcpyAsync(c->d_nwz, nwz, n, hipMemcpyHostToDevice, c->stream));
@@ -765,6 +851,7 @@ int smpc_set_noise(smpc_ctx* c, const float* nvx, const float* nvy, const float*
   c->have_noise = true;
   c->rm_valid = true;
   c->rng_mode = false;
+  c->noise_gen++;
   return SMPC_OK;
 }
 
@@ -785,6 +872,14 @@ int smpc_redraw_noise(smpc_ctx* c)
   HIPCK(c, hipSetDevice(c->device));
   c->epoch++;
   return draw_noise(c);
+}
+
+int smpc_redraw_noise_async(smpc_ctx* c)
+{
+  if (!c) return SMPC_ERR_INVALID;
+  if (!c->rng_mode) return fail(c, SMPC_ERR_STATE, "smpc_redraw_noise_async needs device-RNG mode (smpc_seed)");
+  HIPCK(c, hipSetDevice(c->device));
+  return redraw_async(c);
 }
 
 int smpc_get_noise(smpc_ctx* c, float* nvx, float* nvy, float* nwz)

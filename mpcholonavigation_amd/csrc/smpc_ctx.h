@@ -65,8 +65,8 @@ hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool fu
                                       const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
                                    float neg_inv_temp, hipStream_t st);
-// developer aid: the scoring-pass instance launched last by this thread, as rocprofv3 names it
-extern thread_local char smpc_last_pass_kernel[96];
+// developer aid: the scoring-pass instance launched last, as rocprofv3 names it
+extern char smpc_last_pass_kernel[96];
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);
 
 namespace smpc_impl {
@@ -150,6 +150,20 @@ struct smpc_ctx {
   float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass:
   float* d_tvy = nullptr;       // one allocation, vy and wz follow vx
   float* d_twz = nullptr;
+  // A second set of noise tensors for smpc_redraw_noise_async (regenerate_noises = true): the
+  // next epoch is drawn into it on fill_stream while the host and the device go on; the next
+  // tick's stream waits for ev_fill and the sets change places (absorb_redraw).
+  float* b_nvx = nullptr;
+  float* b_nvy = nullptr;
+  float* b_nwz = nullptr;
+  float* b_tvx = nullptr;       // (one allocation, vy and wz follow vx)
+  float* b_tvy = nullptr;
+  float* b_twz = nullptr;
+  hipStream_t fill_stream = nullptr;
+  hipEvent_t ev_fill = nullptr;
+  bool redraw_pending = false, redraw_rm_valid = true;
+  uint32_t noise_gen = 0;              // counts changes of the noise the ticks score with
+  uint32_t noise_gen_remembered = 0;   // ... as of the last remember_furthest
   bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
   bool rm_valid = true;      // the [B,T] tensors hold the current noise (a device-RNG draw fills the
                              // time-major copy only; ensure_row_major() makes the other on demand)
@@ -337,6 +351,9 @@ uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky);
 int update_time_major(smpc_ctx* c);
 int ensure_row_major(smpc_ctx* c);
 int draw_noise(smpc_ctx* c);
+int redraw_async(smpc_ctx* c);
+int cancel_redraw(smpc_ctx* c);
+int absorb_redraw(smpc_ctx* c);
 
 }  // namespace smpc_impl
 

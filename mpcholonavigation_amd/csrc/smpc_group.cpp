@@ -198,6 +198,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
       if (miss) {
         c->spec_misses++;
         remember_furthest(c, &ins[i], F_true);   // smpc_optimize speculates with the true value now: one pass
+        c->hint_F = F_true;                      // (not the smoothed estimate a fresh-noise tick leaves)
         c->hint_is_this_ticks = true;
       }
       rc = single(i);

@@ -1446,8 +1446,7 @@ __global__ void __launch_bounds__(256) smpc_ackermann_constrain(float* __restric
 // (stands in for xt::random::randn, noise_generator.cpp:107-122).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t& o0,
-                                              uint32_t& o1)
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4])
 {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -1455,66 +1454,86 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
       k0 += 0x9E3779B9u;
       k1 += 0xBB67AE85u;
     }
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // (one 32 x 32 -> 64 multiply each, v_mad_u64_u32: half the quarter-rate instructions of a
+    // v_mul_hi_u32 / v_mul_lo_u32 pair)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0;
     c1 = lo1;
     c2 = n2;
     c3 = lo0;
   }
-  o0 = c0;
-  o1 = c1;
+  o[0] = c0;
+  o[1] = c1;
+  o[2] = c2;
+  o[3] = c3;
 }
 
+// Box–Muller on one pair of Philox words: {radius cos, radius sin} of N(0, 1).  The hardware's
+// log2 and square root (1 ulp) and the rollout's own sin/cos (absolute error 1.3e-7): the normals
+// stay within 1e-6 of the CPU twin's libm evaluation (tests: test_device_rng_matches_cpu_twin),
+// at a third of the instructions of logf / sincosf — with regenerate_noises the draw is 3 x B x T
+// normals per tick.
+__device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float& z0, float& z1)
+{
+  const float u1 = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  // -2 ln u1 = -2 ln 2 log2 u1
+  const float radius = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  float sn, cs;
+  smpc_sincos_fast(6.2831853071795864769f * u2, sn, cs);
+  z0 = radius * cs;
+  z1 = radius * sn;
+}
+
+// Flat elements 4q .. 4q + 3 of a tensor share ONE Philox block (all four words are used: two
+// Box–Muller pairs): thread q of the grid covering [base, base + n).
 __global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, uint64_t n,
                                                       uint64_t base, uint64_t seed,
                                                       uint32_t stream, uint32_t epoch,
                                                       float sigma)
 {
-  // thread q handles global elements 2q, 2q+1 of the pair grid covering [base, base+n)
-  const uint64_t q_first = base >> 1;
-  const uint64_t q_last = (base + n + 1) >> 1;  // exclusive
+  const uint64_t q_first = base >> 2;
+  const uint64_t q_last = (base + n + 3) >> 2;  // exclusive
   for (uint64_t q = q_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_last;
        q += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t r0, r1;
+    uint32_t r[4];
     philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, epoch, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), r0, r1);
-    const float u1 = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float radius = sqrtf(-2.0f * logf(u1));
-    const float ang = 6.2831853071795864769f * u2;
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    const uint64_t e0 = q << 1, e1 = e0 + 1;
-    if (e0 >= base && e0 < base + n) out[e0 - base] = radius * cs * sigma;
-    if (e1 >= base && e1 < base + n) out[e1 - base] = radius * sn * sigma;
+                  (uint32_t)(seed >> 32), r);
+    float z[4];
+    box_muller(r[0], r[1], z[0], z[1]);
+    box_muller(r[2], r[3], z[2], z[3]);
+    const uint64_t e0 = q << 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t e = e0 + (uint64_t)k;
+      if (e >= base && e < base + n) out[e - base] = z[k] * sigma;
+    }
   }
 }
 
 // The same stream written TIME-MAJOR, dst[t * B + b] (the layout the lane-per-rollout pass
-// reads): thread (b, t pair) with b fastest, so a wave writes two coalesced 256-byte row pieces.
-// Element e = row0 * T + b * T + t of the global [B_global, T] tensor is the cos (e even) or sin
-// (e odd) half of Philox pair e / 2 exactly as in smpc_fill_noise; T must be even, so that a
-// pair never straddles two rollouts.
+// reads): thread (b, group of four steps) with b fastest, so a wave writes four coalesced
+// 256-byte row pieces.  Element e = base + b * T + t of the global [B_global, T] tensor is word
+// e % 4 of Philox block e / 4 exactly as in smpc_fill_noise; T must be a multiple of four, so
+// that a block never straddles two rollouts (base is a multiple of T).
 __global__ void __launch_bounds__(256) smpc_fill_noise_tm(float* __restrict__ dst, uint32_t B, uint32_t T,
                                                          uint64_t base, uint64_t seed, uint32_t stream,
                                                          uint32_t epoch, float sigma)
 {
-  const uint64_t n = (uint64_t)B * (T >> 1);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t b = (uint32_t)(i % B), tp = (uint32_t)(i / B);
-    const uint64_t q = (base + (uint64_t)b * T + 2u * tp) >> 1;
-    uint32_t r0, r1;
-    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r0, r1);
-    const float u1 = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float radius = sqrtf(-2.0f * logf(u1));
-    const float ang = 6.2831853071795864769f * u2;
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    dst[(size_t)(2u * tp) * B + b] = radius * cs * sigma;
-    dst[(size_t)(2u * tp + 1u) * B + b] = radius * sn * sigma;
+  // blockIdx.y: the group of four steps; x: rollouts (no 64-bit division of a flat index)
+  const uint32_t tq = blockIdx.y;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const uint64_t q = (base + (uint64_t)b * T + 4u * tq) >> 2;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    float z[4];
+    box_muller(r[0], r[1], z[0], z[1]);
+    box_muller(r[2], r[3], z[2], z[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[(size_t)(4u * tq + (uint32_t)k) * B + b] = z[k] * sigma;
   }
 }
 
@@ -1542,7 +1561,7 @@ hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, 
 // ---------------------------------------------------------------------------
 // launch wrappers (called from smpc_api.cpp through plain C++ linkage)
 // ---------------------------------------------------------------------------
-thread_local char smpc_last_pass_kernel[96] = "";
+char smpc_last_pass_kernel[96] = "";   // (a developer aid: not per thread)
 
 template <int MODE, bool FULL>
 static hipError_t launch_pass_r(int R, const SmpcDev& p, const SmpcLds& L, uint32_t grid,
@@ -1678,18 +1697,18 @@ hipError_t smpc_launch_ackermann(float* u_dev, float* u_host, uint32_t T, float 
 hipError_t smpc_launch_fill_noise_tm(float* dst, uint32_t B, uint32_t T, uint64_t base, uint64_t seed,
                                      uint32_t stream, uint32_t epoch, float sigma, hipStream_t st)
 {
-  const uint64_t n = (uint64_t)B * (T >> 1);
-  uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+  if (T & 3u) return hipErrorInvalidValue;   // a Philox block of four must not straddle two rollouts
+  uint32_t grid = std::min<uint32_t>((B + 255u) / 256u, 2048u);
   if (grid == 0) grid = 1;
-  hipLaunchKernelGGL(smpc_fill_noise_tm, dim3(grid), dim3(256), 0, st, dst, B, T, base, seed, stream, epoch, sigma);
+  hipLaunchKernelGGL(smpc_fill_noise_tm, dim3(grid, T >> 2), dim3(256), 0, st, dst, B, T, base, seed, stream, epoch, sigma);
   return hipGetLastError();
 }
 
 hipError_t smpc_launch_fill_noise(float* out, uint64_t n, uint64_t base, uint64_t seed,
                                   uint32_t stream, uint32_t epoch, float sigma, hipStream_t st)
 {
-  const uint64_t pairs = (n + 3) / 2;
-  uint32_t grid = (uint32_t)((pairs + 255) / 256);
+  const uint64_t blocks4 = (n + 6) / 4;   // (covers a base that is not a multiple of four)
+  uint32_t grid = (uint32_t)((blocks4 + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (grid == 0) grid = 1;
   hipLaunchKernelGGL(smpc_fill_noise, dim3(grid), dim3(256), 0, st, out, n, base, seed, stream,

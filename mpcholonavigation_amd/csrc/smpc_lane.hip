@@ -1131,7 +1131,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   }
 }
 
-extern thread_local char smpc_last_pass_kernel[96];   // smpc_kernels.hip
+extern char smpc_last_pass_kernel[96];   // smpc_kernels.hip
 // the instance's name with every template argument written out, as rocprofv3 prints it
 static void lane_name(bool full, bool obst, bool many, int nch, bool rr, bool ga, bool quads, int tc, bool dep)
 {

@@ -136,15 +136,29 @@ void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F)
   if (trace)
     fprintf(stderr, "[smpc furthest] true %.3f predicted %.3f (geometry %.3f, valid %d, drift %.3f)\n", F,
             c->hint_Fp + c->hint_drift, c->hint_Fp, (int)c->hint_Fp_valid, c->hint_drift);
+  // A tick scored with NEW noise (regenerate_noises = true) moves the extreme rollout by itself:
+  // at 2 097 152 rollouts the true value jitters by +-0.5 of an index from epoch to epoch.  What
+  // the last prediction missed is then mostly that jitter, not a trend: carrying it forward as
+  // drift doubles it (observed: 1.55 scoring passes per tick).  Such ticks update a smoothed
+  // estimate instead — the next prediction starts from F' + 0.4 (F - F'), F' the geometric
+  // prediction of this tick — and leave the drift alone.
+  const bool fresh_noise = c->noise_gen != c->noise_gen_remembered;
+  c->noise_gen_remembered = c->noise_gen;
+  float F_next = F;
   if (c->hint_Fp_valid) {
     const float d = F - c->hint_Fp;
-    c->hint_drift = std::fabs(d) < 2.f ? d : 0.f;
+    if (fresh_noise && std::fabs(d) < 2.f) {
+      F_next = c->hint_Fp + c->hint_drift + 0.4f * (F - (c->hint_Fp + c->hint_drift));
+      c->hint_drift *= 0.5f;
+    } else {
+      c->hint_drift = std::fabs(d) < 2.f ? d : 0.f;
+    }
   } else {
     c->hint_drift = 0.f;
   }
   c->hint_Fp_valid = false;
-  c->hint_F = F;
-  c->hint = smpc_furthest_index(F);
+  c->hint_F = F_next;
+  c->hint = smpc_furthest_index(F_next);
   c->hint_valid = true;
   c->anchor_x = in->pose_x;
   c->anchor_y = in->pose_y;
@@ -522,6 +536,8 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   int rc = check_tick(c, in);
   if (rc != SMPC_OK) return rc;
   if (!u_in) return fail(c, SMPC_ERR_INVALID, "control sequence missing");
+  rc = absorb_redraw(c);   // noise drawn in the background since the last tick, if any
+  if (rc != SMPC_OK) return rc;
   const uint32_t T = c->cfg.time_steps, B = c->cfg.batch_size, P = in->path_len;
   const auto& cr = c->critics;
   HIPCK(c, hipSetDevice(c->device));

@@ -261,8 +261,9 @@ void Optimizer::optimize()
   std::memcpy(control_sequence_.wz.data(), u.data() + 2 * T, T * sizeof(float));
   fail_flag_ = last_out_.fail_flag != 0;
   if (regenerate_noises_ && !supplied_noise_) {
-    // NoiseGenerator::generateNextNoises (noise_generator.cpp:54-63): next tick's noise
-    ck(ctx_, smpc_redraw_noise(ctx_), "smpc_redraw_noise");
+    // NoiseGenerator::generateNextNoises (noise_generator.cpp:54-63): next tick's noise, drawn
+    // while this tick's result travels on (the reference's noise thread, :97-105)
+    ck(ctx_, smpc_redraw_noise_async(ctx_), "smpc_redraw_noise_async");
   }
 }
 

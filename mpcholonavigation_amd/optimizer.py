@@ -139,6 +139,10 @@ class Smpc:
     def redraw_noise(self):
         self._ck(self.lib.smpc_redraw_noise(self.h))
 
+    def redraw_noise_async(self):
+        """The next epoch drawn in the background; the next tick takes it (smpc_redraw_noise_async)."""
+        self._ck(self.lib.smpc_redraw_noise_async(self.h))
+
     def get_noise(self):
         out = [np.empty((self.B, self.T), np.float32) for _ in range(3)]
         self._ck(self.lib.smpc_get_noise(self.h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))

@@ -77,17 +77,19 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 }
 
 // One N(0,1) sample for flat element e of stream s at draw epoch `epoch`.
-// Elements (2q, 2q+1) share one Philox block: Box–Muller cos / sin branch.
+// Elements 4q .. 4q + 3 share one Philox block, all four words used: words (0, 1) give the
+// Box–Muller cos / sin pair of elements 4q, 4q + 1, words (2, 3) that of 4q + 2, 4q + 3.
 inline float normal_sample(uint64_t seed, uint32_t stream, uint32_t epoch, uint64_t e)
 {
-  const uint64_t q = e >> 1;
+  const uint64_t q = e >> 2;
   const uint32_t ctr[4] = {static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), stream,
                            epoch};
   const uint32_t key[2] = {static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
   uint32_t r[4];
   philox4x32_10(ctr, key, r);
-  const float u1 = (static_cast<float>(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float u2 = (static_cast<float>(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const uint32_t w = (e & 2) ? 2u : 0u;
+  const float u1 = (static_cast<float>(r[w] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = (static_cast<float>(r[w + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
   const float radius = sqrtf(-2.0f * logf(u1));
   const float ang = 6.2831853071795864769f * u2;
   return (e & 1) ? radius * sinf(ang) : radius * cosf(ang);

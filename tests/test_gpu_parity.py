@@ -293,6 +293,48 @@ def test_device_rng_matches_cpu_twin(Smpc, Oracle):
     assert np.max(np.abs(g.get_noise()[0] - first)) > 0.1
 
 
+@pytest.mark.parametrize("B,T,flags", [(4096, 64, A.SMPC_FLAG_LANE_PER_ROLLOUT), (4096, 30, 0), (2048, 56, A.SMPC_FLAG_LANE_PER_ROLLOUT)])
+def test_background_redraw_is_the_same_epoch_sequence(Smpc, B, T, flags):
+    """smpc_redraw_noise_async (regenerate_noises = true off the tick's critical path, as the
+    reference's noise thread, noise_generator.cpp:54-63,97-105): the draw goes into a second set of
+    tensors on its own stream, the next tick takes it — bit for bit the ticks and the noise of
+    the synchronous smpc_redraw_noise; a draw nobody took is dropped by smpc_seed."""
+    cfg = default_config(batch_size=B, time_steps=T, flags=flags)
+    scn = make_scenario(T)
+    ctxs = []
+    for _ in range(2):
+        g = Smpc(cfg)
+        g.set_critics(default_critics())
+        g.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
+        g.seed(77)
+        ctxs.append(g)
+    sync, bg = ctxs
+    us = ub = scn.u0
+    for k in range(4):
+        us, os_ = sync.optimize(scn.tick, us)
+        ub, ob = bg.optimize(scn.tick, ub)
+        assert np.array_equal(us, ub), k
+        assert os_.min_cost == ob.min_cost and os_.furthest_reached_path_point == ob.furthest_reached_path_point
+        sync.redraw_noise()
+        bg.redraw_noise_async()
+        bg.redraw_noise_async()          # a second request before a tick took the first: no-op
+    # the draw requested last has not been taken by a tick: get_noise still shows the noise of the last tick ...
+    n_last = [x.copy() for x in bg.get_noise()]
+    ub2, _ = bg.optimize(scn.tick, ub)   # ... and this tick takes it
+    us2, _ = sync.optimize(scn.tick, us)
+    assert np.array_equal(us2, ub2)
+    for a, b in zip(sync.get_noise(), bg.get_noise()):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(n_last[0], bg.get_noise()[0])
+    bg.redraw_noise_async()
+    bg.seed(77)                           # drops the pending draw: epoch 0 of the seed again
+    sync.seed(77)
+    for a, b in zip(sync.get_noise(), bg.get_noise()):
+        assert np.array_equal(a, b)
+    for g in ctxs:
+        g.close()
+
+
 def test_error_paths(Smpc):
     """Error convention: negative status + message, no exception across the ABI."""
     from mpcholonavigation_amd.optimizer import SmpcError
