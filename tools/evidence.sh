@@ -1,0 +1,42 @@
+#!/bin/bash
+# Developer tool: everything under profiles/<round>/ from the binary in the tree, in ONE gpurun call
+# (the boxes of the pool differ; figures that are compared must come from the same box).
+#   tools/evidence.sh r03     -> gpurun_out/evidence_r03/ (copy what is to be judged into profiles/r03/)
+set -u
+R=${1:-r03}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/evidence_$R
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+stats() {   # name, command...
+  local name=$1; shift
+  rm -rf "$OUT/prof_$name"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -- "$@" > "$OUT/$name.stdout" 2> "$OUT/$name.stderr"
+  find "$OUT/prof_$name" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_$name.csv"
+}
+# 1. the bench line, un-profiled, then the same command under the kernel trace
+python3 $ROOT/bench.py > "$OUT/bench_full.json" 2> "$OUT/bench_full.stderr"
+stats bench_2097152x64 python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs
+tail -1 "$OUT/bench_2097152x64.stdout" > "$OUT/bench_under_rocprof.json"
+# 2. the other configurations' scoring passes
+stats cfg1_65536x64 python3 $ROOT/tools/config_ticks.py 65536 64 200 400
+stats cfg2_262144x128_map2000 python3 $ROOT/tools/config_ticks.py 262144 128 2000 200
+stats share_262144x64 python3 $ROOT/tools/config_ticks.py 262144 64 200 400
+stats regenerate_2097152x64 python3 $ROOT/tools/regen_tick.py 2097152 64 60
+# 3. HBM traffic of the headline's scoring pass: separate PMC passes, no trace domains
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf "$OUT/pmc_$C"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 $ROOT/tools/traffic.py 2097152 64 200 > "$OUT/pmc_$C.stdout" 2>&1
+  find "$OUT/pmc_$C" -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} "$OUT/pmc_${C}_2097152x64.csv"
+done
+python3 $ROOT/tools/make_traffic_json.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" 2097152 64 200x200 "$OUT/traffic_2097152x64.json" > /dev/null
+# 4. where a tick's fixed cost goes
+: > "$OUT/tick_timeline.txt"
+for BT in "2000 56" "65536 64" "262144 64"; do
+  rm -rf "$OUT/tl"
+  rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/tl" -- python3 $ROOT/tools/tick_timeline.py run $BT 400 > /dev/null 2>&1
+  echo "== tick timeline $BT" >> "$OUT/tick_timeline.txt"
+  python3 $ROOT/tools/tick_timeline.py report "$OUT/tl" >> "$OUT/tick_timeline.txt"
+done
+rm -rf "$OUT/tl" "$OUT"/prof_* "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
+ls -la "$OUT"
