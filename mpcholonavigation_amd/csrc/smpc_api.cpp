@@ -193,10 +193,12 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   // wave-per-rollout pass instead (its geometry is planned for every tick).
   const bool lane = c->lane_now && !(flags & SD_STORE_TRAJ) &&
     !(c->lane_rr && !(flags & (SD_OBSTACLES | SD_COST)));
-  if (lane) nblk = c->grid_tpr;
+  // (the split form scores the plain five with ObstaclesCritic on: a tick whose flags were stripped takes the lane pass)
+  const bool split = lane && c->split_now && (flags & SD_OBSTACLES) && !(flags & (SD_GOAL_ANGLE | SD_EXTRA_CRITICS));
+  if (lane) nblk = split ? c->grid_split : c->grid_tpr;
   // The block that finishes last reduces the partials inside the scoring launch (smpc_tail.h);
   // larger grids, and launches whose LDS was not sized for it, take the separate reduction.
-  const bool tail = c->fused_reduce && nblk <= SMPC_TAIL_MAX_GRID && (!lane || c->lane_block == smpc_lane_block()) &&
+  const bool tail = !split && c->fused_reduce && nblk <= SMPC_TAIL_MAX_GRID && (!lane || c->lane_block == smpc_lane_block()) &&
     (lane ? c->lds_tpr.total : c->lds.total) >= smpc_tail_lds_bytes(d.T);
   // completion words: one per block of smpc_reduce_partials, or per reducing block of the tail
   c->poll_words = (fin.enabled && fin.done_counter) ? (4u + 3u * d.T + 31u) / 32u : 0u;
@@ -215,7 +217,10 @@ int launch_score(smpc_ctx* c, uint32_t flags, const float* u_dev, const float* d
   }
   c->launched = true;
   // the lane-per-rollout pass scores with the full lean critic stack only
-  if (lane) {
+  if (split) {
+    HIPCK(c, smpc_launch_pass_split(d, c->lds_split, nblk, c->split_nseg, c->stream));
+    c->last_pass_kind = 2;
+  } else if (lane) {
     HIPCK(c, smpc_launch_pass_lane(d, c->lds_tpr, nblk, c->lane_rr, c->lane_block, c->stream));
     c->last_pass_kind = 1;
   } else {
@@ -608,12 +613,28 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
     // which streaming pass: a wave per rollout (latency, small batches) or a lane per
     // rollout (throughput, large batches); SMPC_PASS=wave|lane overrides for experiments
     bool tpr = cfg->batch_size >= kLaneMinBatch && cfg->time_steps <= kLaneMaxT;
+    // (smpc_pass_split, T = 64: the time-major noise from kSplitMinBatch rollouts up; plan_launch keeps
+    // the lane pass itself for batches from kLaneMinBatch up, unless it is asked for)
+    if (cfg->time_steps == 64 && cfg->batch_size >= kSplitMinBatch && !getenv("SMPC_NO_SPLIT")) tpr = true;
     if (cfg->flags & SMPC_FLAG_WAVE_PER_ROLLOUT) tpr = false;
-    if (cfg->flags & SMPC_FLAG_LANE_PER_ROLLOUT) tpr = true;
+    if (cfg->flags & SMPC_FLAG_LANE_PER_ROLLOUT) {
+      tpr = true;
+      c->lane_forced = true;
+    }
     if (const char* e = getenv("SMPC_PASS")) {
       if (!strcmp(e, "wave")) tpr = false;
-      if (!strcmp(e, "lane")) tpr = true;
+      if (!strcmp(e, "lane")) {
+        tpr = true;
+        c->lane_forced = true;
+      }
+      if (!strcmp(e, "split")) {
+        tpr = true;
+        c->lane_forced = true;
+        c->knob_force_split = true;
+      }
     }
+    c->knob_no_split = getenv("SMPC_NO_SPLIT") != nullptr;
+    if (const char* e = getenv("SMPC_SPLIT_NSEG")) c->knob_split_nseg = static_cast<uint32_t>(std::max(0, atoi(e)));
     if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) tpr = false;   // visualisation path: wave pass
     if (3ull * n >= (1ull << 32)) tpr = false;   // its buffer descriptor spans the three noise tensors
     c->use_tpr = tpr;
@@ -623,6 +644,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
       c->d_tvy = c->d_tvx + n / sizeof(float);
       c->d_twz = c->d_tvy + n / sizeof(float);
       CK(smpc_lane_set_lds_limit(static_cast<int>(kLdsPerCu)));
+      CK(smpc_split_set_lds_limit(static_cast<int>(kLdsPerCu)));
     }
   }
   CK(hipMalloc(&c->d_costs[0], cfg->batch_size * sizeof(float)));
@@ -1102,6 +1124,21 @@ int smpc_selftest_lane_reduce(smpc_ctx* c, const float* v, const float* w, float
   (void)hipFree(dv); (void)hipFree(dw); (void)hipFree(dout);
   return SMPC_OK;
 }
+int smpc_selftest_row_reduce(smpc_ctx* c, const float* v, uint32_t n, float* out)
+{
+  if (!c || !v || !out || (n != 16 && n != 32)) return fail(c, SMPC_ERR_INVALID, "bad argument");
+  HIPCK(c, hipSetDevice(c->device));
+  float *dv = nullptr, *dout = nullptr;
+  HIPCK(c, hipMalloc(&dv, 64 * n * sizeof(float)));
+  HIPCK(c, hipMalloc(&dout, 64 * sizeof(float)));
+  HIPCK(c, hipMemcpyAsync(dv, v, 64 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, smpc_launch_row_reduce(dv, dout, n, c->stream));
+  HIPCK(c, hipMemcpyAsync(out, dout, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dv); (void)hipFree(dout);
+  return SMPC_OK;
+}
+
 int smpc_set_stream(smpc_ctx* c, void* hip_stream)
 {
   if (!c) return SMPC_ERR_INVALID;

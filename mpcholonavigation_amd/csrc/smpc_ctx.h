@@ -61,6 +61,13 @@ hipError_t smpc_lane_occupancy(bool full, uint32_t lds_bytes, int* blocks_per_cu
 hipError_t smpc_lane_occupancy_rr(uint32_t T, uint32_t lds_bytes, int* blocks_per_cu);
 hipError_t smpc_lane_set_lds_limit(int bytes);
 hipError_t smpc_launch_lane_reduce(const float* v, const float* w, float* out, hipStream_t st);
+// smpc_split.hip: lane = (rollout, quarter of the horizon), for batches of at most one round of waves
+hipError_t smpc_launch_pass_split(const SmpcDev& p, const SmpcLds& L, uint32_t grid, uint32_t nseg, hipStream_t st);
+hipError_t smpc_launch_row_reduce(const float* v, float* out, uint32_t n, hipStream_t st);
+uint32_t smpc_split_block();
+uint32_t smpc_split_rollouts_per_block(uint32_t nseg);
+hipError_t smpc_split_occupancy(uint32_t nseg, uint32_t lds_bytes, int* blocks_per_cu);
+hipError_t smpc_split_set_lds_limit(int bytes);
 hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst, bool dep, uint32_t T,
                                       const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
@@ -92,6 +99,8 @@ const RcclApi* rccl();   // smpc_shard.cpp; null when RCCL cannot be loaded
 // partial (fewer partials to reduce); T > 128 needs more registers per lane than 16 waves allow
 inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
 constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
+constexpr uint32_t kSplitMinBatch = 12u * 1024u;  // smpc_pass_split (T = 64) from this batch size up to one group per wave (measured: 16 384 x 64
+                                                  // 38.9 -> 36.2 us per tick, 32 768: 44.7 -> 36.7; 4 096: no gain)
 constexpr uint32_t kLaneMaxT = 128;       // T <= 64: 3 x 64 noised controls parked per lane (or re-read); T <= 128: re-read
 constexpr uint32_t kPollWords = 32;     // completion words behind h_out[3T + 8] (T = 256: 25 blocks of smpc_reduce_partials)
 constexpr uint32_t kMaxGrid = SMPC_MAX_GRID;   // smpc_reduce_partials stages this many factors
@@ -168,6 +177,16 @@ struct smpc_ctx {
   bool rm_valid = true;      // the [B,T] tensors hold the current noise (a device-RNG draw fills the
                              // time-major copy only; ensure_row_major() makes the other on demand)
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
+  bool split_now = false;    // ... as smpc_pass_split (lane = rollout x quarter of the horizon): small batches at T = 64
+  SmpcLds lds_split{};
+  uint32_t grid_split = 0;
+  uint32_t split_nseg = 4;               // lanes per rollout of this tick's split pass: 4 or 2
+  int occ_split_blocks = -1;
+  uint32_t occ_split_lds = 0xffffffffu;
+  uint32_t knob_split_nseg = 0;          // SMPC_SPLIT_NSEG=2|4: experiments
+  bool lane_forced = false;              // SMPC_FLAG_LANE_PER_ROLLOUT / SMPC_PASS=lane|split: the lane pass below kLaneMinBatch too
+  bool knob_no_split = false;            // SMPC_NO_SPLIT=1
+  bool knob_force_split = false;         // SMPC_PASS=split: wherever the instance applies, whatever the batch
   bool lane_rr = false;      // ... in its re-read form (no parked controls; T > 64 or SMPC_LANE_REREAD=1)
   uint32_t last_pass_kind = 0;
   // member of a smpc_group: the group uploads every member's tick block in one copy
@@ -327,6 +346,7 @@ TickLayout tick_layout(uint32_t T, uint32_t P);
 SmpcLds make_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nwave, bool with_map,
                  uint32_t nsamp = 0);
 SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T, bool rr = false);
+SmpcLds split_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nseg);
 
 int check_tick(smpc_ctx* c, const smpc_tick_in* in);
 // the furthest point F (index + fraction) is now known for the tick inputs `in`: the next

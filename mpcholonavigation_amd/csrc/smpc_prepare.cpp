@@ -73,6 +73,21 @@ SmpcLds lane_lds(uint32_t window_bytes, uint32_t P, uint32_t T, bool rr)
   return Lt;
 }
 
+// LDS layout of smpc_pass_split: as the lane pass up to the path points, then sum u^2 [4] and the
+// control sequence [3][64] in front of the per-wave scratch (parked wz [16][64]; the block
+// combine's tuple re-uses it)
+SmpcLds split_lds(uint32_t window_bytes, uint32_t P, uint32_t T, uint32_t nseg)
+{
+  const uint32_t lblock = smpc_split_block();
+  SmpcLds Lt = make_lds(window_bytes ? window_bytes + 1 + lblock : 0, P, T, lblock / 64, window_bytes != 0, 0);
+  Lt.off_pts4 = Lt.off_scr;
+  Lt.off_scr += align_up(std::max(P, 1u) * 16, 16) + 16 + 3 * 64 * 4;
+  // parked wz [steps per lane][64]; two segments: vy too (smpc_split.hip PARK_VY)
+  Lt.scr_stride = align_up(std::max((nseg == 2 ? 2u : 1u) * (64u / nseg) * 64u, 4u + 3u * T), 4);
+  Lt.total = Lt.off_scr + (lblock / 64) * Lt.scr_stride * 4;
+  return Lt;
+}
+
 // distanceToObstacle (obstacles_critic.cpp:99-112) for an 8-bit cost, point mode
 static float distance_to_obstacle(const HostCostmap& m, float cost, bool using_footprint = false)
 {
@@ -526,6 +541,50 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     const double eps = 2.0 * (u24 * xmax * rinv + 3.0 * u24 * qmax + e_c * rinv) + 1e-7;
     d.cell_eps_w = static_cast<float>(std::min(eps, 0.5));
   }
+
+  // Small batches at T = 64: while the waves of smpc_pass_split (16 rollouts, four lanes each) have
+  // at most two groups each, the horizon split over four lanes runs the tick's one scoring pass in
+  // a fraction of a 64-step chain (65 536 x 64: one wave per SIMD on the lane pass).  The plain five
+  // critics only; the geometry above (window, cell index constants) is shared.
+  c->split_now = false;
+  if (c->lane_now && !c->lane_rr && !lane_ga && !lane_dep && mode_now == 0 && T == 64 && (gates & SD_OBSTACLES) &&
+      !c->in_group && !c->knob_no_split && !c->fused_reduce && (!c->lane_forced || c->knob_force_split)) {
+    // (a context that ASKS for the lane pass — SMPC_FLAG_LANE_PER_ROLLOUT, SMPC_PASS=lane — gets it)
+    // one block per CU (two waves per SIMD: the kernel's registers), and ONE group per wave: four
+    // lanes per rollout while 16-rollout groups fit (32 768 rollouts on 256 CUs), two up to twice that
+    const uint32_t waves = static_cast<uint32_t>(c->num_cu) * (smpc_split_block() / 64u);
+    // (the two-segment instance — 32 steps per lane, up to 65 536 rollouts at one group per wave —
+    // is built and parity-tested but not selected: its arrays spill 340 bytes per lane at 256
+    // registers and the tick takes 70.9 us where the lane pass takes 48.5; SMPC_SPLIT_NSEG=2)
+    uint32_t nseg = 0;
+    if ((B + 15u) / 16u <= waves) nseg = 4;
+    if (c->knob_split_nseg == 2 || c->knob_split_nseg == 4) nseg = (nseg || c->knob_force_split) ? c->knob_split_nseg : 0;
+    if (!nseg && c->knob_force_split) nseg = 4;
+    if (nseg) {
+      const SmpcLds Ls = split_lds(window_bytes, P, T, nseg);
+      if (Ls.total <= kLdsPerCu) {
+        const uint32_t key = Ls.total ^ (nseg << 28);
+        if (c->occ_split_lds != key) {
+          int nb = 0;
+          if (smpc_split_occupancy(nseg, Ls.total, &nb) != hipSuccess || nb < 1) nb = 1;
+          c->occ_split_blocks = nb;
+          c->occ_split_lds = key;
+        }
+        const uint32_t per_block = smpc_split_rollouts_per_block(nseg);
+        const uint32_t blocks = (B + per_block - 1) / per_block;
+        const uint32_t resident = static_cast<uint32_t>(c->num_cu) * static_cast<uint32_t>(c->occ_split_blocks);
+        c->split_now = true;
+        c->split_nseg = nseg;
+        c->lds_split = Ls;
+        c->grid_split = std::max(1u, std::min(std::min(blocks, resident), kMaxGrid));   // (persistent: forced runs loop over groups)
+      }
+    }
+  }
+
+  // below kLaneMinBatch the lane pass itself loses to the wave pass (one group per CU's worth of
+  // waves: crossover measured at ~50 k rollouts); such contexts keep the time-major noise only
+  // for the split form
+  if (c->lane_now && !c->split_now && B < kLaneMinBatch && !c->lane_forced) c->lane_now = false;
 
   mode_out = mode_now;
   return SMPC_OK;

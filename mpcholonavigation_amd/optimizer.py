@@ -186,6 +186,16 @@ class Smpc:
         return out
 
     # ---- batch-sharded phases (device pointers are plain ints) ------------------
+    def selftest_row_reduce(self, v):
+        """smpc_split.hip's N x N transpose-reduce per group of N lanes: v [64 lanes][N] -> [64], N = 16 or 32."""
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        out = np.empty(64, np.float32)
+        f = self.lib.smpc_selftest_row_reduce
+        f.restype = C.c_int
+        f.argtypes = [A._ctx, C.c_void_p, C.c_uint32, C.c_void_p]
+        self._ck(f(self.h, _ptr(v), v.shape[1], _ptr(out)))
+        return out
+
     def set_stream(self, hip_stream):
         self._ck(self.lib.smpc_set_stream(self.h, C.c_void_p(hip_stream)))
 

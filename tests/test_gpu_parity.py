@@ -416,6 +416,45 @@ def test_device_sincos_accuracy(Smpc):
     assert np.max(np.abs(s.astype(np.float64) ** 2 + c.astype(np.float64) ** 2 - 1.0)) < 4e-7
 
 
+def test_row_transpose_reduce(Smpc):
+    """smpc_pass_split's 16 x 16 transpose-reduce inside every 16-lane DPP row: lane i of a row
+    gets the sum over the row's lanes of their register i — exact on integers."""
+    g = Smpc(default_config(batch_size=64, time_steps=8))
+    rng = np.random.default_rng(12)
+    for n in (16, 32):
+        v = rng.integers(-8, 9, size=(64, n)).astype(np.float32)
+        got = g.selftest_row_reduce(v)
+        want = np.concatenate([v[n * s:n * s + n].sum(axis=0) for s in range(64 // n)])
+        assert np.array_equal(got, want), n
+
+
+@pytest.mark.parametrize("B,M,nseg", [(16384, 200, 0), (4096, 200, 2), (65536, 200, 0), (1000, 200, 0), (16400, 2000, 0),
+                                      (70000, 200, 4), (70000, 200, 2), (32768, 200, 0)])
+def test_split_horizon_pass_parity(Smpc, Oracle, B, M, nseg, monkeypatch):
+    """smpc_pass_split (lane = rollout x quarter of the horizon, the small-batch form at T = 64):
+    parity with the oracle over three closed-loop ticks — the first without a furthest-point
+    prediction (furthest-only pass in front), then speculated; ragged batches (tail lanes), more
+    groups than waves (70 000: forced), a costmap larger than the LDS window."""
+    monkeypatch.setenv("SMPC_PASS", "split")
+    if nseg:
+        monkeypatch.setenv("SMPC_SPLIT_NSEG", str(nseg))     # (else the library's choice: 4 lanes per rollout up to 32 768, then 2)
+    cfg, scn, noise = make_case(B, 64, map_size=M)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+    ug = uo = scn.u0
+    for k in range(3):
+        t = scn.tick
+        tk = Tick(t.pose_x + 0.02 * k, t.pose_y, t.pose_yaw, t.speed, t.path_x, t.path_y, t.path_yaw, t.goal_x, t.goal_y)
+        ug, og = g.optimize(tk, uo)
+        uo, oo = o.optimize(tk, uo)
+        assert og.pass_kind == 2, og.pass_kind
+        assert og.non_colliding == oo.non_colliding
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"split {B} map {M} tick {k}",
+                      report=(k == 0))
+        uo = np.concatenate([uo[:, 1:], uo[:, -1:]], axis=1)
+
+
 def test_lane_transpose_reduce(Smpc):
     """The in-register 64 x 64 transpose-reduce (v_permlane32/16_swap + bank-masked DPP) of
     the lane-per-rollout pass: exact on integers, and lane t really gets column t."""
