@@ -141,8 +141,12 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
   constexpr int SPLIT_SEG = 64 / NSEG;    // steps per lane
   constexpr int SPLIT_ROLL = 64 / NSEG;   // rollouts per wave
   constexpr int NSAMP = SPLIT_SEG / 4;    // PathAlign samples per lane
-  // two segments: 32 steps per lane — the noised vy is parked in LDS next to wz (vx, the segment's
-  // displacements and PathAlign's samples fill the registers: with vy there too 91 of them spill)
+  // two segments: 32 steps per lane — the noised vy is parked in LDS next to wz.  (This instance
+  // still spills 340 bytes per lane at 256 registers, and not because of what is live: without
+  // the exact cell path's BRANCH in each of the 32 unrolled critic steps it needs 242 registers and
+  // no scratch, whatever that path computes — a division-free form, a uniform branch only, no
+  // global fetch: all tried, 332-384 bytes.  The allocator loses the plot across 32 conditional
+  // blocks.  Built and parity-tested, not selected by the host: plan_launch.)
   constexpr bool PARK_VY = NSEG == 2;
   const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
