@@ -65,6 +65,12 @@ __global__ void k_publish(const uint32_t* __restrict__ partial, uint32_t* __rest
   }
 }
 
+// the same result as {value, sequence number} in ONE 8-byte store: no fence, no separate flag
+__global__ void k_publish_pair(const uint32_t* __restrict__ partial, unsigned long long* __restrict__ host_out, uint32_t seq)
+{
+  if (threadIdx.x == 0) host_out[1] = ((unsigned long long)seq << 32) | partial[0];
+}
+
 // both in one launch: block 0 publishes its own sum (the floor of a single submission)
 __global__ void k_one(const uint32_t* __restrict__ tick, uint32_t* __restrict__ host_out, uint32_t seq)
 {
@@ -240,6 +246,21 @@ int main(int argc, char** argv)
       want = fill_bar(b.p, k);
       hipLaunchKernelGGL(k_one, dim3(grid), dim3(256), 0, st, b.p, h_out_dev, ++seq);
       return wait_seq(h_out, seq);
+    });
+  }
+  if (bar_plain) {
+    run("BAR + 2 launches, pair store", [&](uint32_t k, uint32_t& want) {
+      want = fill_bar(d_tick, k);
+      hipLaunchKernelGGL(k_score, dim3(grid), dim3(256), 0, st, d_tick, d_partial, spin);
+      hipLaunchKernelGGL(k_publish_pair, dim3(1), dim3(64), 0, st, d_partial, reinterpret_cast<unsigned long long*>(h_out_dev), ++seq);
+      volatile unsigned long long* hp = reinterpret_cast<volatile unsigned long long*>(h_out);
+      const double t0 = now_us();
+      while ((uint32_t)(hp[1] >> 32) != seq) {
+        __builtin_ia32_pause();
+        if (now_us() - t0 > 2.0e6) return false;
+      }
+      h_out[0] = (uint32_t)hp[1];   // (where the checker looks)
+      return true;
     });
   }
   // how long the CPU stores themselves take
