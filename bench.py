@@ -502,7 +502,10 @@ def main():
         from mpcholonavigation_amd.sharded import (HipShard, MailboxShardedOptimizer, NativeShardedOptimizer,
                                                    ShardedOptimizer)
         labels = {
-            "rccl": "RCCL called from libsmpc (smpc_shard_tick: ncclAllGather on the ctx's stream)",
+            "rccl": ("RCCL called from libsmpc (smpc_shard_tick: ncclAllGather on the ctx's stream)"
+                     if not os.environ.get("SMPC_RCCL_LIB") else
+                     "NOT RCCL: the nccl* entry points of smpc_shard_tick come from SMPC_RCCL_LIB="
+                     + os.environ["SMPC_RCCL_LIB"] + " (a rehearsal of the control flow, not a measurement)"),
             "mailbox": "mailboxes over IPC/xGMI, no collective (smpc_shard_p2p_*, smpc_shard_tick)",
             "torch": "RCCL through torch.distributed (ShardedOptimizer)",
         }
