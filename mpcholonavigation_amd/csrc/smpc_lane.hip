@@ -59,6 +59,9 @@
 #ifndef LANE_X_GAMMA_UC
 #define LANE_X_GAMMA_UC 1    // gamma terms as sum u c - sum u^2 (one fma per control and step; the constant from LDS)
 #endif
+#ifndef LANE_X_FURTHEST_WINDOW
+#define LANE_X_FURTHEST_WINDOW 1   // the endpoint's nearest-path-point scan from three blocks below the scored index up, the rest verified for the wave's winner
+#endif
 #ifndef LANE_X_PFW_MIN
 #define LANE_X_PFW_MIN 1     // PreferForward as -dt sum min(vx, 0)
 #endif
@@ -799,7 +802,15 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       float best = 3.4028234663852886e38f;
       uint32_t bj = 0;
       const uint32_t P4 = (p.P + 3u) & ~3u;
-      for (uint32_t j = 0; j < P4; j += 4) {
+      // The scan is 15 blocks for a 60-point path and only its batch-wide MAXIMUM is consumed.  So
+      // it starts three blocks below the block of the index this tick is scored with (where the
+      // maximum has been every tick so far) and runs to the path's end; what that leaves out is
+      // checked for the ONE lane that ends up holding the wave's maximum (below).  (The plain
+      // instances only: in the GoalAngle, deployed-list and grouped ones the extra code costs
+      // 16-48 bytes of scratch.)
+      constexpr bool kWindow = LANE_X_FURTHEST_WINDOW && !GA && !DEP && !MANY;
+      const uint32_t j_lo = (kWindow && (S >> 2) > 3u) ? ((S >> 2) - 3u) << 2 : 0u;
+      for (uint32_t j = j_lo; j < P4; j += 4) {
         float dd[4];
         block_d2(s_px + j, s_py + j, dd);
         const float mn = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
@@ -808,22 +819,60 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
           bj = j;
         }
       }
-      float dd[4];
-      block_d2(s_px + bj, s_py + bj, dd);
-      const uint32_t bi = bj + (dd[0] == best ? 0u : dd[1] == best ? 1u : dd[2] == best ? 2u : dd[3] == best ? 3u : 0u);
       // index + how far the endpoint sits towards the next point, in segment lengths (what the
       // host predicts the next tick's index from; smpc_dev.h)
-      float F = (float)bi;
-      if (bi + 1 < p.P) {
-        const float nx = s_px[bi + 1], ny = s_py[bi + 1];
-        const float sgx = nx - s_px[bi], sgy = ny - s_py[bi];
-        const float d_next = (nx - x) * (nx - x) + (ny - y) * (ny - y);
-        const float seg2 = sgx * sgx + sgy * sgy;
-        const float tt = seg2 > 0.f ? 0.5f + 0.5f * (best - d_next) * fast_rcp(seg2) : 0.f;
-        F = fmaxf(F + fminf(fmaxf(tt, -0.45f), 0.45f), 0.f);
-      }
+      auto point_F = [&]() -> float {
+        float dd[4];
+        block_d2(s_px + bj, s_py + bj, dd);
+        const uint32_t bi = bj + (dd[0] == best ? 0u : dd[1] == best ? 1u : dd[2] == best ? 2u : dd[3] == best ? 3u : 0u);
+        float F = (float)bi;
+        if (bi + 1 < p.P) {
+          const float nx = s_px[bi + 1], ny = s_py[bi + 1];
+          const float sgx = nx - s_px[bi], sgy = ny - s_py[bi];
+          const float d_next = (nx - x) * (nx - x) + (ny - y) * (ny - y);
+          const float seg2 = sgx * sgx + sgy * sgy;
+          const float tt = seg2 > 0.f ? 0.5f + 0.5f * (best - d_next) * fast_rcp(seg2) : 0.f;
+          F = fmaxf(F + fminf(fmaxf(tt, -0.45f), 0.45f), 0.f);
+        }
+        return F;
+      };
+      float F = point_F();
       float m = live ? F : 0.f;
       for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+      if (kWindow && j_lo) {
+        // A lane whose true nearest point lies BELOW the window holds a value that is too high,
+        // never too low: max over the lanes of the windowed values >= the true maximum, with
+        // equality as soon as ONE lane that attains it is exact.  So: take a lane holding the
+        // maximum and test every point below the window against its endpoint — one point per
+        // lane of the wave, "<=" because an equal distance at a lower index wins the reference's
+        // strict scan.  If one of them beats it (a path that doubles back under the endpoint),
+        // every lane scans the lower blocks after all and the maximum is formed again.
+        const unsigned long long holders = __ballot(live && F == m);
+        bool below = false;
+        if (holders) {
+          const int wl = __builtin_ctzll(holders);
+          const float wx = __shfl(x, wl, WAVE), wy = __shfl(y, wl, WAVE), wbest = __shfl(best, wl, WAVE);
+          for (uint32_t k = (uint32_t)lane; k < j_lo; k += WAVE) {
+            const float ex = s_px[k] - wx, ey = s_py[k] - wy;
+            below = below || (ex * ex + ey * ey <= wbest);
+          }
+        }
+        if (__builtin_expect(__any(below), 0)) {
+          for (uint32_t jj = j_lo; jj > 0; jj -= 4) {      // downwards: ties go to the lower block
+            const uint32_t j = jj - 4;
+            float dd[4];
+            block_d2(s_px + j, s_py + j, dd);
+            const float mn = fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3]));
+            if (mn <= best) {
+              best = mn;
+              bj = j;
+            }
+          }
+          F = point_F();
+          m = live ? F : 0.f;
+          for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+        }
+      }
       F_local = fmaxf(F_local, m);
     }
     // costs (every cost_power == 1): the lean association of smpc_pass MODE 0

@@ -455,6 +455,52 @@ def test_split_horizon_pass_parity(Smpc, Oracle, B, M, nseg, monkeypatch):
         uo = np.concatenate([uo[:, 1:], uo[:, -1:]], axis=1)
 
 
+def test_windowed_furthest_scan_falls_back_exactly(Smpc, Oracle):
+    """The lane pass scans the endpoint's nearest path point from three blocks below the scored
+    index up and verifies the rest for the wave's winner (smpc_lane.hip).  Paths on which that
+    window is wrong: (1) a plan that doubles back, so that points far apart in index are close in
+    space; (2) a tick whose plan has three times the spacing of the last one while the speculated
+    index still comes from the old plan — every rollout's true nearest point then lies BELOW the
+    window and every wave has to fall back.  The furthest reached path point is an integer output:
+    exact, tick after tick."""
+    B, T = 4096, 64
+    cfg, scn, noise = make_case(B, T)
+    cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+    t = scn.tick
+    P = len(t.path_x)
+    res = float(t.path_x[1] - t.path_x[0])
+    # (1) out along +x for 34 points, then back along -x, 0.05 m to the side
+    k = np.arange(P)
+    out_x = t.path_x[0] + res * np.minimum(k, 33)
+    back = np.maximum(k - 33, 0)
+    ux = (out_x - res * back).astype(np.float32)
+    uy = (t.path_y[0] + np.where(k > 33, 0.05, 0.0)).astype(np.float32)
+    uturn = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, ux, uy, np.zeros(P, np.float32), float(ux[-1]), float(uy[-1]))
+    # (2) the same straight plan at three times the spacing
+    cx = (t.path_x[0] + 3.0 * res * k).astype(np.float32)
+    coarse = Tick(t.pose_x, t.pose_y, t.pose_yaw, t.speed, cx, t.path_y.copy(), np.zeros(P, np.float32), float(cx[-1]),
+                  float(t.path_y[-1]))
+    u = scn.u0
+    seen = []
+    for label, tk in (("straight", t), ("straight", t), ("u-turn", uturn), ("u-turn", uturn), ("straight", t),
+                      ("coarse", coarse), ("coarse", coarse), ("straight", t)):
+        ug, og = g.optimize(tk, u)
+        uo, oo = o.optimize(tk, u)
+        assert og.pass_kind == 1
+        assert og.furthest_reached_path_point == oo.furthest_reached_path_point, (label, seen)
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=1, label=f"window {label}", report=False)
+        seen.append((label, int(og.furthest_reached_path_point), int(og.passes)))
+        u = np.concatenate([uo[:, 1:], uo[:, -1:]], axis=1)
+    print("[windowed furthest scan] (plan, furthest point, scoring passes):", seen)
+    # the coarse plan's furthest point lies below the window the straight plan's index opens
+    straight = [f for l, f, _ in seen if l == "straight"][0]
+    coarse_f = [f for l, f, _ in seen if l == "coarse"][0]
+    assert coarse_f + 12 < straight, seen
+
+
 def test_lane_transpose_reduce(Smpc):
     """The in-register 64 x 64 transpose-reduce (v_permlane32/16_swap + bank-masked DPP) of
     the lane-per-rollout pass: exact on integers, and lane t really gets column t."""

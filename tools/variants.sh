@@ -10,7 +10,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-u
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   ( /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize -Wno-pass-failed $defs -c -o ../variants/lane_$name.o smpc_lane.hip
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libsmpc_$name.so smpc_kernels.o ../variants/lane_$name.o \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libsmpc_$name.so smpc_kernels.o ../variants/lane_$name.o smpc_split.o \
         smpc_api.o smpc_prepare.o smpc_shard.o smpc_group.o -Wl,-rpath,/opt/rocm/lib
     echo built $name ) &
 done
