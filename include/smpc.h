@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 1
+#define SMPC_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 #define SMPC_OK 0
@@ -224,7 +224,7 @@ typedef struct smpc_velocity_deadband_params {
 } smpc_velocity_deadband_params;
 
 /* Scoring order (CriticManager scores in list order and stops at the first critic that
- * sets fail_flag, critic_manager.cpp:67-76): Constraint, Cost, Obstacles, PathAlign,
+ * sets fail_flag, critic_manager.cpp:67-76): Constraint, Cost, Obstacles, PathAlign, PathAlignLegacy,
  * PathFollow, GoalAngle, PreferForward, Goal, PathAngle, Twirling, VelocityDeadband.  A
  * different YAML order changes float summation order (last bits) and which costs the
  * discarded all-collide tick carries, nothing else. */
@@ -240,6 +240,10 @@ typedef struct smpc_critic_params {
   smpc_twirling_params twirling;
   smpc_path_angle_params path_angle;
   smpc_velocity_deadband_params velocity_deadband;
+  /* PathAlignLegacyCritic (path_align_legacy_critic.cpp:26-44: the parameters of PathAlignCritic,
+   * the pre-October-2023 formulation: every trajectory sample against its nearest path point by
+   * brute force, :84-124), scored right behind PathAlign by the general pass.  ABI version 2. */
+  smpc_path_align_params path_align_legacy;
 } smpc_critic_params;
 
 /*

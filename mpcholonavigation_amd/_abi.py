@@ -6,7 +6,7 @@ to the CPU oracle, so one set of inputs feeds both.
 """
 import ctypes as C
 
-SMPC_ABI_VERSION = 1
+SMPC_ABI_VERSION = 2
 
 SMPC_OK = 0
 SMPC_ERR_INVALID = -1
@@ -188,6 +188,7 @@ class SmpcCriticParams(C.Structure):
         ("twirling", SmpcTwirlingParams),
         ("path_angle", SmpcPathAngleParams),
         ("velocity_deadband", SmpcVelocityDeadbandParams),
+        ("path_align_legacy", SmpcPathAlignParams),
     ]
 
 

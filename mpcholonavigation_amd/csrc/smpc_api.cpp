@@ -525,6 +525,7 @@ void smpc_critic_params_default(smpc_critic_params* p)
   p->twirling = {0, 1, 10.0f};
   p->path_angle = {0, 1, 2.0f, 4, 0.5f, 1.2f, 1, -0.35f};
   p->velocity_deadband = {0, 1, 35.0f, {0.0f, 0.0f, 0.0f}};
+  p->path_align_legacy = {0, 0, 1, 10.0f, 0.07f, 20, 4, 0.5f};   // path_align_legacy_critic.cpp:26-37
 }
 
 int smpc_abi_version(void) {return SMPC_ABI_VERSION;}

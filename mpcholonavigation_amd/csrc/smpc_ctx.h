@@ -338,7 +338,7 @@ void free_ctx(smpc_ctx* c);
 
 // tick block layout (offsets in bytes), sized for the ctx's T and SMPC_MAX_PATH
 struct TickLayout {
-  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, pang_active, lut_cost, canary, total;
+  size_t u, px, py, pyaw, D, pf_idx, pvalid, pa_active, pang_active, pal_active, lut_cost, canary, total;
 };
 TickLayout tick_layout(uint32_t T, uint32_t P);
 

@@ -25,8 +25,10 @@
 #define SD_DEADBAND 0x10000u
 #define SD_FP_OBSTACLES 0x20000u   // ObstaclesCritic consider_footprint
 #define SD_FP_COST 0x40000u        // CostCritic consider_footprint
+#define SD_PATH_ALIGN_LEGACY 0x80000u   // PathAlignLegacyCritic past its host-side gates (still gated per S)
+#define SD_PAL_USE_PATH_YAW 0x100000u  // ... with use_path_orientations
 #define SD_EXTRA_CRITICS (SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE | SD_DEADBAND | \
-                          SD_FP_OBSTACLES | SD_FP_COST)
+                          SD_FP_OBSTACLES | SD_FP_COST | SD_PATH_ALIGN_LEGACY)
 
 #define SMPC_MAX_PATH 1024        // path points staged in LDS
 #define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
@@ -125,6 +127,9 @@ struct SmpcDev {
   float pang_weight;
   uint32_t pang_power, pang_offset;
   int32_t pang_correct;                          // reversing allowed and no forward preference
+  const uint8_t* pal_active;                     // [P] PathAlignLegacy gate per candidate furthest point
+  float pal_weight, pal_eval;                    // cost_weight; floor(T / trajectory_point_step) (path_align_legacy_critic.cpp:83)
+  uint32_t pal_power;
   double db_vx, db_vy, db_wz;                    // |deadband_velocities|
   float db_weight;
   uint32_t db_power;
@@ -163,7 +168,7 @@ struct SmpcDev {
   // (smpc_tick_ptrs).  tick_inline = 0: the pointers above (device memory) are used.
   uint32_t tick_inline;        // the path and its tables are in tick_bytes
   uint32_t u_inline;           // u is in u_arg (0: p.u, e.g. the previous iteration's result on the device)
-  uint16_t io_px, io_py, io_pyaw, io_D, io_pf_idx, io_pvalid, io_pa_active, io_pang_active;
+  uint16_t io_px, io_py, io_pyaw, io_D, io_pf_idx, io_pvalid, io_pa_active, io_pang_active, io_pal_active, io_pad;
   uint8_t tick_bytes[1536] __attribute__((aligned(16)));
   // The control sequence u[3][T] of a tick with T <= 64 (u_inline).  Only the wave-per-rollout
   // pass, which reads u once, takes its tick block from the kernel arguments; the
@@ -192,10 +197,11 @@ struct SmpcTickPtrs {
   const uint8_t* pvalid;
   const uint8_t* pa_active;
   const uint8_t* pang_active;
+  const uint8_t* pal_active;
 };
 __device__ __forceinline__ SmpcTickPtrs smpc_tick_ptrs(const SmpcDev& p, bool kernarg_is_dev)
 {
-  SmpcTickPtrs t{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active};
+  SmpcTickPtrs t{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active, p.pal_active};
 #if defined(__HIP_DEVICE_COMPILE__)
   if (kernarg_is_dev && p.tick_inline) {
     const uint8_t* k = reinterpret_cast<const uint8_t*>(__builtin_amdgcn_kernarg_segment_ptr()) +
@@ -210,6 +216,7 @@ __device__ __forceinline__ SmpcTickPtrs smpc_tick_ptrs(const SmpcDev& p, bool ke
     t.pvalid = k + p.io_pvalid;
     t.pa_active = k + p.io_pa_active;
     t.pang_active = k + p.io_pang_active;
+    t.pal_active = k + p.io_pal_active;
   }
 #else
   (void)kernarg_is_dev;

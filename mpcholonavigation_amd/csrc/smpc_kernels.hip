@@ -358,6 +358,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
 
   uint32_t S = 0;       // batch-wide furthest point used for scoring
   bool pa_on = false;
+  bool pal_on = false;  // PathAlignLegacyCritic (general pass only)
   float pf_x = 0.f, pf_y = 0.f;
   uint32_t bs_iters = 0;
   float pa_inv_spacing = 0.f;   // (S-1) / D[S-1]: mean inverse spacing of the plan
@@ -367,6 +368,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       if (S >= p.P) S = p.P ? p.P - 1 : 0;
     }
     pa_on = (p.flags & SD_PATH_ALIGN) && p.P > 0 && tk.pa_active[S] && S > 0;
+    if (GENERIC) pal_on = (p.flags & SD_PATH_ALIGN_LEGACY) && p.P > 1 && tk.pal_active[S];
     if ((p.flags & SD_PATH_FOLLOW) && p.P > 0) {
       const uint32_t idx = tk.pf_idx[S];
       pf_x = s_px[idx];
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
   for (int r = 0; r < R; ++r) {
     const uint32_t t = t0 + r;
     const uint32_t q = p.step ? t / p.step : 0u;
-    slot[r] = (pa_on && p.step && STEP_OK(r) && q * p.step == t && q <= K) ? (int)q : -1;
+    slot[r] = ((pa_on || pal_on) && p.step && STEP_OK(r) && q * p.step == t && q <= K) ? (int)q : -1;
   }
   const uint32_t end_lane = (T - 1) / R, end_r = (T - 1) % R;
 
@@ -507,6 +509,40 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
       const float c_pa = num > 0.f ? (GENERIC ? summed / num : summed * fast_rcp(num)) : 0.f;
       if (GENERIC) cost = add_cost_pow(cost, (double)(c_pa * p.pa_weight), p.pa_power);
       else cost += c_pa * pa_w;
+    }
+    // ---- PathAlignLegacyCritic (path_align_legacy_critic.cpp:74-129), lane = (rollout g, sample s):
+    // every trajectory point step, 2 step, ... against its nearest path point by brute force over
+    // s' = 0 .. P - 3 (the loop runs to path_segments_count - 1 EXCLUSIVE, :101), first minimum
+    // wins; the point counts unless it is point 0 or invalid (:119-121); the sum is divided by
+    // floor(T / step), not by the count (:124)
+    if (GENERIC && pal_on) {
+      const bool smp = rowon && s >= 1 && s <= K;
+      const float Tx = pts_x[lane], Ty = pts_y[lane];
+      float min_dist_sq = 3.4028234663852886e38f;
+      uint32_t min_s = 0;
+      const uint32_t n_pts = p.P - 2u;      // (P >= 2: the host's gate)
+      for (uint32_t q = 0; q < n_pts; ++q) {
+        const float dx = s_px[q] - Tx, dy = s_py[q] - Ty;
+        float dist_sq = dx * dx + dy * dy;
+        if (p.flags & SD_PAL_USE_PATH_YAW) {
+          // angles::shortest_angular_distance(P_yaw(s), T_yaw(t, p)) = normalize_angle(to - from)
+          const double dd = (double)pts_yaw[lane] - (double)s_pyaw[q];
+          double a = fmod(fmod(dd, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+          if (a > M_PI) a -= 2.0 * M_PI;
+          const float dyaw = (float)a;
+          dist_sq = dx * dx + dy * dy + dyaw * dyaw;
+        }
+        if (dist_sq < min_dist_sq) {
+          min_dist_sq = dist_sq;
+          min_s = q;
+        }
+      }
+      const bool ok = smp && min_s != 0u && s_valid[min_s];
+      const float d = ok ? sqrtf(min_dist_sq) : 0.f;
+      const float dsum = seg_scan_add(d, seg_shift);
+      const float summed = __shfl(dsum, lane | (int)(SEG - 1), WAVE);
+      const float c_pal = summed / p.pal_eval;
+      cost = add_cost_pow(cost, (double)(c_pal * p.pal_weight), p.pal_power);
     }
     // costs_ [B]: one lane per parked rollout
     if (rowon && s == 0) p.costs[b_last - (n - 1 - g) * nW] = cost;
@@ -1039,7 +1075,7 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
           const uint32_t q = (n_pend << seg_shift) + (uint32_t)slot[r];
           pts_x[q] = x[r];
           pts_y[q] = y[r];
-          if (RARE && (p.flags & SD_USE_PATH_YAW)) pts_yaw[q] = yaw[r];
+          if (RARE && (p.flags & (SD_USE_PATH_YAW | SD_PAL_USE_PATH_YAW))) pts_yaw[q] = yaw[r];
         }
       }
       if (((uint32_t)lane >> seg_shift) == n_pend) pend_cost = cost;

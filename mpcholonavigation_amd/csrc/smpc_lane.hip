@@ -172,7 +172,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // (this pass reads its tick block from device memory only: it fetches u with scalar loads quad
   // by quad, group after group, and reads of the kernarg segment are not cached the way plain
   // device memory is — u inside the kernel arguments cost the 2 097 152-rollout pass 7 %)
-  const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active};
+  const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active, p.pal_active};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);

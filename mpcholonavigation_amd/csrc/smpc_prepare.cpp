@@ -22,6 +22,7 @@ TickLayout tick_layout(uint32_t T, uint32_t P)
   l.pvalid = o; o += align_up(P, 16);
   l.pa_active = o; o += align_up(P, 16);
   l.pang_active = o; o += align_up(P, 16);
+  l.pal_active = o; o += align_up(P, 16);   // PathAlignLegacy gate per candidate furthest point
   l.lut_cost = o; o += 256 * 4;   // CostCritic repulsive term per 8-bit cost
   l.total = o;
   return l;
@@ -306,6 +307,10 @@ static int tick_gates(smpc_ctx* c, const smpc_tick_in* in, uint32_t& gates_out, 
     !within_tol(cr.path_angle.threshold_to_consider, rx, ry, gx, gy))
     gates |= SD_PATH_ANGLE;                                   // path_angle_critic.cpp:60-69
   if (cr.velocity_deadband.enabled) gates |= SD_DEADBAND;
+  // PathAlignLegacyCritic (path_align_legacy_critic.cpp:48-54, :86-88: at least one path segment)
+  if (cr.path_align_legacy.enabled && P >= 2 &&
+    !within_tol(cr.path_align_legacy.threshold_to_consider, rx, ry, gx, gy))
+    gates |= SD_PATH_ALIGN_LEGACY;
   if (P == 0) gates &= ~(SD_PATH_ALIGN | SD_PATH_FOLLOW);
   uint32_t nsamp = 0;
   const uint32_t step = cr.path_align.trajectory_point_step;
@@ -317,7 +322,21 @@ static int tick_gates(smpc_ctx* c, const smpc_tick_in* in, uint32_t& gates_out, 
     if (nsamp == 0) gates &= ~SD_PATH_ALIGN;  // no samples: cost 0 for every rollout
     if (cr.path_align.use_path_orientations) gates |= SD_USE_PATH_YAW;
   }
-  if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW | SD_PATH_ANGLE)) gates |= SD_NEED_FURTHEST;
+  if (gates & SD_PATH_ALIGN_LEGACY) {
+    // its trajectory points are PathAlign's: p = step, 2 step, ... < T (path_align_legacy_critic.cpp:97)
+    const uint32_t lstep = cr.path_align_legacy.trajectory_point_step;
+    if ((gates & SD_PATH_ALIGN) && lstep != step)
+      return fail(c, SMPC_ERR_UNSUPPORTED,
+                  "PathAlignCritic and PathAlignLegacyCritic in one list need the same trajectory_point_step");
+    const uint32_t ns = lstep > 0 ? (T - 1) / lstep : 0;
+    if (ns > 63)
+      return fail(c, SMPC_ERR_UNSUPPORTED,
+                  "PathAlignLegacy: more than 63 samples per trajectory (time_steps / trajectory_point_step)");
+    if (ns == 0) gates &= ~SD_PATH_ALIGN_LEGACY;   // no samples: summed_dist 0, cost 0 for every rollout
+    else nsamp = ns;
+    if (cr.path_align_legacy.use_path_orientations && (gates & SD_PATH_ALIGN_LEGACY)) gates |= SD_PAL_USE_PATH_YAW;
+  }
+  if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW | SD_PATH_ANGLE | SD_PATH_ALIGN_LEGACY)) gates |= SD_NEED_FURTHEST;
   if (c->map.track_unknown) gates |= SD_TRACK_UNKNOWN;
   if (c->cfg.flags & SMPC_FLAG_STORE_TRAJECTORIES) gates |= SD_STORE_TRAJ;
 
@@ -336,7 +355,7 @@ static void path_tables(const smpc_ctx* c, const smpc_tick_in* in, uint32_t gate
   const uint32_t nseg = P > 0 ? P - 1 : 0;
   if (in->path_pts_valid) {
     memcpy(pvalid, in->path_pts_valid, nseg);
-  } else if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW)) {
+  } else if (gates & (SD_PATH_ALIGN | SD_PATH_FOLLOW | SD_PATH_ALIGN_LEGACY)) {
     for (uint32_t i = 0; i < nseg; ++i) {
       unsigned mx, my;
       uint8_t v = 1;
@@ -623,7 +642,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   rc = tick_gates(c, in, gates, nsamp);
   if (rc != SMPC_OK) return rc;
   const double rx = in->pose_x, ry = in->pose_y, gx = in->goal_x, gy = in->goal_y;
-  const uint32_t step = cr.path_align.trajectory_point_step;
+  // (PathAlignLegacy alone: its own step — tick_gates refuses two different ones)
+  const uint32_t step = (gates & SD_PATH_ALIGN) || !(gates & SD_PATH_ALIGN_LEGACY) ? cr.path_align.trajectory_point_step
+                                                                                    : cr.path_align_legacy.trajectory_point_step;
   path_tables(c, in, gates, px, py, pvalid, D);
 
   // ---- per-candidate-furthest-point tables -------------------------------------
@@ -646,7 +667,9 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     if (world_to_map(c->map, x00, y00, mx, my))
       cost_t0 = c->map.cells[static_cast<size_t>(my) * c->map.W + mx];
   }
-  if (gates & SD_PATH_ALIGN) {
+  // PathAlignCritic's and PathAlignLegacyCritic's gate per candidate furthest point S
+  // (path_align_critic.cpp:58-74, path_align_legacy_critic.cpp:56-72: the same code)
+  auto occupancy_gate = [&](const smpc_path_align_params& q, uint8_t* active) {
     // utils::findPathTrajectoryInitialPoint (tools/utils.hpp:327-344)
     size_t init = 0;
     float best = std::numeric_limits<float>::max();
@@ -658,28 +681,27 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
         init = j;
       }
     }
-    // :64-74 occupancy of the path between the initial and the furthest point.  The
-    // reference walks i = init..S-1 with a running count of invalid points and stops at the
-    // first i where count / range > ratio and count > 2; the count only grows and range is
-    // fixed per S, so that happens iff it holds for the final count: prefix sums, O(P).
+    // occupancy of the path between the initial and the furthest point.  The reference
+    // walks i = init..S-1 with a running count of invalid points and stops at the first i where
+    // count / range > ratio and count > 2; the count only grows and range is fixed per S, so
+    // that happens iff it holds for the final count: prefix sums, O(P).
     std::vector<uint32_t> inval(P + 1, 0);
     for (uint32_t i = 0; i < P; ++i) inval[i + 1] = inval[i] + ((i + 1 < P && !pvalid[i]) ? 1u : 0u);
     for (uint32_t S = 0; S < P; ++S) {
-      bool on = S >= cr.path_align.offset_from_furthest;     // path_align_critic.cpp:58-61
+      bool on = S >= q.offset_from_furthest;
       if (on && S > init) {
         const unsigned int invalid_ctr = inval[S] - inval[init];
         const float range = static_cast<float>(static_cast<size_t>(S) - init);
-        if (static_cast<float>(invalid_ctr) / range > cr.path_align.max_path_occupancy_ratio &&
-          invalid_ctr > 2)
-        {
-          on = false;
-        }
+        if (static_cast<float>(invalid_ctr) / range > q.max_path_occupancy_ratio && invalid_ctr > 2) on = false;
       }
-      pa_active[S] = on ? 1 : 0;
+      active[S] = on ? 1 : 0;
     }
-  } else {
-    memset(pa_active, 0, std::max(P, 1u));
-  }
+  };
+  if (gates & SD_PATH_ALIGN) occupancy_gate(cr.path_align, pa_active);
+  else memset(pa_active, 0, std::max(P, 1u));
+  uint8_t* pal_active = h + tl.pal_active;
+  if (gates & SD_PATH_ALIGN_LEGACY) occupancy_gate(cr.path_align_legacy, pal_active);
+  else memset(pal_active, 0, std::max(P, 1u));
   if (gates & SD_PATH_FOLLOW) {
     // path_follow_critic.cpp:46-57
     const size_t path_size = P - 1;
@@ -872,6 +894,13 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   d.goal_weight = cr.goal.cost_weight; d.goal_power = cr.goal.cost_power;
   d.tw_weight = cr.twirling.cost_weight; d.tw_power = cr.twirling.cost_power;
   d.pang_active = tb + tl.pang_active;
+  d.pal_active = tb + tl.pal_active;
+  d.pal_weight = cr.path_align_legacy.cost_weight;
+  d.pal_power = cr.path_align_legacy.cost_power;
+  {
+    const uint32_t lstep = cr.path_align_legacy.trajectory_point_step;
+    d.pal_eval = lstep ? static_cast<float>(T / lstep) : 0.f;   // traj_pts_eval = floor(T / step) (:83)
+  }
   d.pang_weight = cr.path_angle.cost_weight; d.pang_power = cr.path_angle.cost_power;
   d.pang_offset = cr.path_angle.offset_from_furthest; d.pang_correct = pang_correct ? 1 : 0;
   d.db_vx = std::fabs(static_cast<double>(cr.velocity_deadband.deadband_velocities[0]));
@@ -923,6 +952,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
     d.io_pyaw = static_cast<uint16_t>(tl.pyaw - o); d.io_D = static_cast<uint16_t>(tl.D - o);
     d.io_pf_idx = static_cast<uint16_t>(tl.pf_idx - o); d.io_pvalid = static_cast<uint16_t>(tl.pvalid - o);
     d.io_pa_active = static_cast<uint16_t>(tl.pa_active - o); d.io_pang_active = static_cast<uint16_t>(tl.pang_active - o);
+    d.io_pal_active = static_cast<uint16_t>(tl.pal_active - o);
     memcpy(d.tick_bytes, h + o, tl.lut_cost - o);
   }
   d.partials = c->d_partials;

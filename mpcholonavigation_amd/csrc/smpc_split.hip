@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
   // global fetch: all tried, 332-384 bytes.  The allocator loses the plot across 32 conditional
   // blocks.  Built and parity-tested, not selected by the host: plan_launch.)
   constexpr bool PARK_VY = NSEG == 2;
-  const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active};
+  const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active, p.pal_active};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint8_t* s_map = smem;
   const SmpcLut* s_lut = reinterpret_cast<const SmpcLut*>(smem + L.off_lut);

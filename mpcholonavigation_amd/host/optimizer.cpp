@@ -94,7 +94,7 @@ void Optimizer::initialize(
   p.obstacles.enabled = p.path_align.enabled = p.path_follow.enabled = 0;
   p.goal_angle.enabled = p.prefer_forward.enabled = 0;
   p.cost.enabled = p.goal.enabled = p.constraint.enabled = p.twirling.enabled = 0;
-  p.path_angle.enabled = p.velocity_deadband.enabled = 0;
+  p.path_angle.enabled = p.velocity_deadband.enabled = p.path_align_legacy.enabled = 0;
   for (const auto & name : critics_.critics) {
     if (name == "ObstaclesCritic") {
       p.obstacles.enabled = 1;
@@ -118,9 +118,13 @@ void Optimizer::initialize(
       p.path_angle.enabled = 1;
     } else if (name == "VelocityDeadbandCritic") {
       p.velocity_deadband.enabled = 1;
+    } else if (name == "PathAlignLegacyCritic") {
+      p.path_align_legacy.enabled = 1;
     } else {
+      // (critics.xml registers twelve classes and all twelve are fused: what is left is a name
+      // pluginlib would not find either, critic_manager.cpp:45-57)
       throw std::runtime_error(
-              "Critic sortham::critics::" + name + " is registered but not fused on the MI355X path");
+              "Critic sortham::critics::" + name + " is not one of the registered critic classes (critics.xml)");
     }
   }
 

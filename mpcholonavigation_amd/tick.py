@@ -124,4 +124,8 @@ def default_critics() -> A.SmpcCriticParams:
     pa.forward_preference, pa.vx_min = 1, -0.35
     vd = p.velocity_deadband  # src/critics/velocity_deadband_critic.cpp:24-33
     vd.enabled, vd.cost_power, vd.cost_weight = 0, 1, 35.0
+    lg = p.path_align_legacy  # src/critics/path_align_legacy_critic.cpp:26-37
+    lg.enabled, lg.use_path_orientations, lg.cost_power, lg.cost_weight = 0, 0, 1, 10.0
+    lg.max_path_occupancy_ratio, lg.offset_from_furthest = 0.07, 20
+    lg.trajectory_point_step, lg.threshold_to_consider = 4, 0.5
     return p

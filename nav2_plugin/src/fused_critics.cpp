@@ -3,11 +3,9 @@
 // critic_function.hpp, pluginlib, nav2_costmap_2d); NOT built by this repository's
 // tests — see INTEGRATION.md.
 //
-// The eleven critics on the MI355X path read exactly the parameters their reference
-// initialize() reads (same names, same defaults) and publish them to
-// FusedCriticRegistry; score() does nothing because libsmpc scores inside the
-// fused kernel.  PathAlignLegacyCritic stays loadable but refuses to be configured, so a
-// YAML that lists it fails loudly instead of silently dropping a cost term.
+// The twelve critics read exactly the parameters their reference initialize() reads (same
+// names, same defaults) and publish them to FusedCriticRegistry; score() does nothing because
+// libsmpc scores inside the fused kernels.
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -162,19 +160,19 @@ for (size_t k = 0; k < 3 && k < deadband.size(); ++k) {
 }
 FUSED_CRITIC_END
 
-#define UNFUSED_CRITIC(Class)                                                                  \
-  class Class : public CriticFunction                                                          \
-  {                                                                                            \
-public:                                                                                        \
-    void score(CriticData &) override {}                                                       \
-    void initialize() override                                                                 \
-    {                                                                                          \
-      throw std::runtime_error(                                                                \
-              #Class " is registered but not fused on the MI355X path"); \
-    }                                                                                          \
-  };
-
-UNFUSED_CRITIC(PathAlignLegacyCritic)
+FUSED_CRITIC_BEGIN(PathAlignLegacyCritic)   // ref src/critics/path_align_legacy_critic.cpp:26-37
+auto & p = e.params.path_align_legacy;
+bool use_path_orientations = false;
+p.enabled = enabled_;
+getParam(p.cost_power, "cost_power", 1);
+getParam(p.cost_weight, "cost_weight", 10.0);
+getParam(p.max_path_occupancy_ratio, "max_path_occupancy_ratio", 0.07);
+getParam(p.offset_from_furthest, "offset_from_furthest", 20);
+getParam(p.trajectory_point_step, "trajectory_point_step", 4);
+getParam(p.threshold_to_consider, "threshold_to_consider", 0.5);
+getParam(use_path_orientations, "use_path_orientations", false);
+p.use_path_orientations = use_path_orientations;
+FUSED_CRITIC_END
 
 }  // namespace sortham::critics
 

@@ -896,6 +896,89 @@ void score_path_align(smpc_oracle * o, const Tick & tk)
   }
 }
 
+// PathAlignLegacyCritic (src/critics/path_align_legacy_critic.cpp:46-129): the pre-October-2023
+// formulation — every trajectory sample against its nearest path point, by brute force
+void score_path_align_legacy(smpc_oracle * o, const Tick & tk)
+{
+  const auto & p = o->critics.path_align_legacy;
+  // :48-54 not close to the goal
+  if (!p.enabled || within_position_goal_tolerance(
+      p.threshold_to_consider, tk.in->pose_x, tk.in->pose_y, tk.in->goal_x, tk.in->goal_y))
+  {
+    return;
+  }
+  // :56-60 not while first getting bearing w.r.t. the path
+  set_path_furthest_if_not_set(o, tk);
+  if (o->furthest < p.offset_from_furthest) {
+    return;
+  }
+  // :62-72 not when obstacles block a significant part of the local path
+  set_path_costs_if_not_set(o, tk);
+  const size_t B = o->B(), T = o->T();
+  const size_t closest_initial_path_point =
+    find_path_trajectory_initial_point(o->tx[0], o->ty[0], tk.px, tk.py, tk.P);
+  unsigned int invalid_ctr = 0;
+  const float range = static_cast<float>(o->furthest - closest_initial_path_point);
+  for (size_t i = closest_initial_path_point; i < o->furthest; i++) {
+    if (!o->path_pts_valid[i]) {invalid_ctr++;}
+    if (static_cast<float>(invalid_ctr) / range > p.max_path_occupancy_ratio && invalid_ctr > 2) {
+      return;
+    }
+  }
+  // :78-88 P_x / P_y / P_yaw = the path without its last point
+  const float * P_x = tk.px;
+  const float * P_y = tk.py;
+  const float * P_yaw = tk.pyaw;
+  const size_t step = p.trajectory_point_step;
+  if (step == 0 || tk.P < 1) {return;}     // (floor(T / 0) in the reference: undefined; a path tensor always has a point)
+  const size_t traj_pts_eval = T / step;   // floor(time_steps / trajectory_point_step_)
+  const size_t path_segments_count = tk.P - 1;
+  if (path_segments_count < 1) {
+    return;
+  }
+  std::vector<float> cost(B, 0.0f);
+  float dist_sq = 0.0f, dx = 0.0f, dy = 0.0f, dyaw = 0.0f, summed_dist = 0.0f;
+  float min_dist_sq = std::numeric_limits<float>::max();
+  size_t min_s = 0;
+  for (size_t t = 0; t < B; ++t) {
+    summed_dist = 0.0f;
+    const float * T_x = &o->tx[t * T];
+    const float * T_y = &o->ty[t * T];
+    const float * T_yaw = &o->tyaw[t * T];
+    for (size_t q = step; q < T; q += step) {
+      min_dist_sq = std::numeric_limits<float>::max();
+      min_s = 0;
+      // :100-114 the closest path point (the loop stops one short of the last segment's start)
+      for (size_t s = 0; s + 1 < path_segments_count; s++) {
+        dx = P_x[s] - T_x[q];
+        dy = P_y[s] - T_y[q];
+        if (p.use_path_orientations) {
+          // angles::shortest_angular_distance(from, to) = normalize_angle(to - from) (ros/angles; unpinned)
+          const double d = static_cast<double>(T_yaw[q]) - static_cast<double>(P_yaw[s]);
+          double a = std::fmod(std::fmod(d, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+          if (a > M_PI) {a -= 2.0 * M_PI;}
+          dyaw = static_cast<float>(a);
+          dist_sq = dx * dx + dy * dy + dyaw * dyaw;
+        } else {
+          dist_sq = dx * dx + dy * dy;
+        }
+        if (dist_sq < min_dist_sq) {
+          min_dist_sq = dist_sq;
+          min_s = s;
+        }
+      }
+      // :116-121 the point must not be in collision (and point 0 never counts)
+      if (min_s != 0 && o->path_pts_valid[min_s]) {
+        summed_dist += sqrtf(min_dist_sq);
+      }
+    }
+    cost[t] = summed_dist / traj_pts_eval;
+  }
+  for (size_t i = 0; i < B; ++i) {
+    add_cost_pow(o->costs[i], cost[i] * p.cost_weight, p.cost_power);
+  }
+}
+
 // PathFollowCritic (src/critics/path_follow_critic.cpp:35-71)
 void score_path_follow(smpc_oracle * o, const Tick & tk)
 {
@@ -1259,9 +1342,9 @@ struct CriticEntry {
   CriticFn fn;
   bool collision;   // sets fail_flag
 };
-const CriticEntry kCriticOrder[11] = {
+const CriticEntry kCriticOrder[12] = {
   {score_constraint, false}, {score_cost, true}, {score_obstacles, true},
-  {score_path_align, false}, {score_path_follow, false}, {score_goal_angle, false},
+  {score_path_align, false}, {score_path_align_legacy, false}, {score_path_follow, false}, {score_goal_angle, false},
   {score_prefer_forward, false}, {score_goal, false}, {score_path_angle, false},
   {score_twirling, false}, {score_velocity_deadband, false}};
 bool collision_critic_enabled(const smpc_oracle * o, CriticFn fn)
@@ -1858,6 +1941,7 @@ int smpc_oracle_score_critic(smpc_oracle * o, int critic_id, const smpc_tick_in 
     case SMPC_ORACLE_CRITIC_TWIRLING: score_twirling(o, tk); break;
     case SMPC_ORACLE_CRITIC_PATH_ANGLE: score_path_angle(o, tk); break;
     case SMPC_ORACLE_CRITIC_VELOCITY_DEADBAND: score_velocity_deadband(o, tk); break;
+    case SMPC_ORACLE_CRITIC_PATH_ALIGN_LEGACY: score_path_align_legacy(o, tk); break;
     default: return fail(o, SMPC_ERR_INVALID, "unknown critic id");
   }
   memcpy(costs_inout, o->costs.data(), B * sizeof(float));
@@ -2011,6 +2095,7 @@ void smpc_critic_params_default(smpc_critic_params * p)
   memset(p, 0, sizeof(*p));
   p->obstacles = {1, 0, 1, 1.5f, 20.0f, 10000.0f, 0.10f, 0.5f};       // obstacles_critic.cpp:21-31
   p->path_align = {1, 0, 1, 10.0f, 0.07f, 20, 4, 0.5f};               // path_align_critic.cpp:26-38
+  p->path_align_legacy = {0, 0, 1, 10.0f, 0.07f, 20, 4, 0.5f};        // path_align_legacy_critic.cpp:26-37
   p->path_follow = {1, 1, 5.0f, 1.4f, 6};                             // path_follow_critic.cpp:23-33
   p->goal_angle = {1, 1, 3.0f, 0.5f};                                 // goal_angle_critic.cpp:20-27
   p->prefer_forward = {1, 1, 5.0f, 0.5f};                             // prefer_forward_critic.cpp:20-27

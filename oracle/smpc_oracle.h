@@ -31,6 +31,7 @@ typedef struct smpc_oracle smpc_oracle;
 #define SMPC_ORACLE_CRITIC_TWIRLING 8
 #define SMPC_ORACLE_CRITIC_PATH_ANGLE 9
 #define SMPC_ORACLE_CRITIC_VELOCITY_DEADBAND 10
+#define SMPC_ORACLE_CRITIC_PATH_ALIGN_LEGACY 11
 
 int smpc_oracle_create(const smpc_config* cfg, smpc_oracle** out);
 void smpc_oracle_destroy(smpc_oracle* o);

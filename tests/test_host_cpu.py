@@ -57,10 +57,11 @@ def test_configuration_errors_match_reference_messages(host):
         for model in ("DiffDrive", "Ackermann"):
             with pytest.raises(RuntimeError, match="no HIP device"):
                 host.Optimizer(cfg, cr, controller_frequency=20.0, motion_model=model)
-    # a registered critic that is not fused must not be silently dropped
-    with pytest.raises(RuntimeError, match="PathAlignLegacyCritic"):
+    # a name that is not one of the twelve registered critic classes must not be silently dropped
+    # (pluginlib would fail to load it, critic_manager.cpp:45-57)
+    with pytest.raises(RuntimeError, match="ObstacleCritic is not one of the registered"):
         host.Optimizer(cfg, cr, controller_frequency=20.0,
-                       critics=["ObstaclesCritic", "PathAlignLegacyCritic"])
+                       critics=["ObstacleCritic", "PathAlignLegacyCritic"])
 
 
 def test_host_needs_a_gpu(host):

@@ -18,7 +18,7 @@ from oracle import loader
 from oracle.loader import Oracle, ptr
 
 CRITIC = dict(obstacles=0, path_align=1, path_follow=2, goal_angle=3, prefer_forward=4, cost=5, goal=6,
-              constraint=7, twirling=8, path_angle=9, velocity_deadband=10)
+              constraint=7, twirling=8, path_angle=9, velocity_deadband=10, path_align_legacy=11)
 
 
 def _tick(pose_x=0.0, pose_y=0.0, yaw=0.0, speed=(0.0, 0.0, 0.0), path=None, goal=(0.0, 0.0),
@@ -459,6 +459,50 @@ def test_path_align_critic_kat():
     path[0][:] = 1.5
     path[1][:] = 1.5
     _score(o, "path_align", _tick(pose_x=0.0, path=path, goal=(1.5, 0.0)), costs, 21)
+    assert abs(float(costs.sum())) < 1e-6
+
+
+def test_path_align_legacy_critic_kat():
+    """critics_tests.cpp:564-660: near -> 0; furthest < 20 -> 0; furthest 21 on an empty 10-point
+    path and zero trajectories -> 0; the 22-point path with every trajectory at x = 0.66 -> 400
+    ("0.04 * 1000 * 10 weight * 6 num pts eval / 6 normalization term"); lethal island -> 0."""
+    B, T = 1000, 30
+    o = Oracle(default_config(batch_size=B, time_steps=T, model_dt=0.1))
+    cr = default_critics()
+    cr.path_align_legacy.enabled = 1
+    o.set_critics(cr)
+    cells = _blank_costmap(o)
+    path = [np.zeros(10, np.float32) for _ in range(3)]
+    path[0][9] = 0.85
+    costs = np.zeros(B, np.float32)
+    _score(o, "path_align_legacy", _tick(pose_x=1.0, path=path, goal=(0.85, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    # far enough, but the furthest point reached is 0 < offset_from_furthest (20)
+    path[0][9] = 0.15
+    _score(o, "path_align_legacy", _tick(pose_x=1.0, path=path, goal=(0.15, 0.0)), costs)
+    assert abs(float(costs.sum())) < 1e-6
+    # :615-620 presets furthest = 21 on the 10-point path; the occupancy walk would index the
+    # validity vector out of range there (UB in the reference): the oracle refuses, as for PathAlign
+    rc, _ = _score(o, "path_align_legacy", _tick(pose_x=1.0, path=path, goal=(0.15, 0.0)), costs, 21)
+    assert rc == A.SMPC_ERR_INVALID
+    # the 22-point path, trajectories at x = 0.66: the nearest of points 0..19 is point 7 (0.7), 0.04 away,
+    # for each of the 7 samples p = 4..28; floor(30 / 4) = 7 divides  ->  0.04 * 10 per rollout
+    path = [np.zeros(22, np.float32) for _ in range(3)]
+    path[0][:10] = [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+    path[0][10:] = 0.9
+    tx = np.full((B, T), 0.66, np.float32)
+    o.lib.smpc_oracle_set_trajectories(o.h, ptr(tx), None, None)
+    rc, _ = _score(o, "path_align_legacy", _tick(pose_x=0.0, path=path, goal=(0.9, 0.0)), costs, 21)
+    assert rc == 0
+    assert abs(float(costs.astype(np.float64).sum()) - 400.0) < 1e-2
+    # lethal island: path blocked -> critic stands down
+    cells[11:31, 11:31] = 254
+    o.set_costmap(cells, 0.0, 0.0, 0.1, inscribed_radius=0.0, cost_scaling_factor=0.0,
+                  inflation_radius=0.0)
+    costs[:] = 0
+    path[0][:] = 1.5
+    path[1][:] = 1.5
+    _score(o, "path_align_legacy", _tick(pose_x=0.0, path=path, goal=(1.5, 0.0)), costs, 21)
     assert abs(float(costs.sum())) < 1e-6
 
 
