@@ -573,8 +573,8 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     // lanes per rollout while 16-rollout groups fit (32 768 rollouts on 256 CUs), two up to twice that
     const uint32_t waves = static_cast<uint32_t>(c->num_cu) * (smpc_split_block() / 64u);
     // (the two-segment instance — 32 steps per lane, up to 65 536 rollouts at one group per wave —
-    // is built and parity-tested but not selected: its arrays spill 340 bytes per lane at 256
-    // registers and the tick takes 70.9 us where the lane pass takes 48.5; SMPC_SPLIT_NSEG=2)
+    // is built and parity-tested but not selected: a half chain at twice the instructions per
+    // step, 50.0 us per tick at 65 536 x 64 where the lane pass takes 49.9; SMPC_SPLIT_NSEG=2)
     uint32_t nseg = 0;
     if ((B + 15u) / 16u <= waves) nseg = 4;
     if (c->knob_split_nseg == 2 || c->knob_split_nseg == 4) nseg = (nseg || c->knob_force_split) ? c->knob_split_nseg : 0;

@@ -53,6 +53,13 @@
 // group: 4 up to 32 768 rollouts on 256 CUs, 2 up to 65 536.
 
 typedef const float __attribute__((address_space(4))) * cfloat_ps;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <int N> struct vecN;
+template <> struct vecN<32> {typedef f32x32 type;};
+template <> struct vecN<16> {typedef f32x16 type;};
+template <> struct vecN<8> {typedef f32x8 type;};
+template <> struct vecN<4> {typedef f32x4 type;};
 
 // 16 x 16 transpose-reduce inside every 16-lane DPP row: in: V[i] of lane r; out: lane i of the
 // row = sum_r V_r[i].  The four within-row levels of smpc_lane_common.h's 64-lane butterfly.
@@ -141,12 +148,15 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
   constexpr int SPLIT_SEG = 64 / NSEG;    // steps per lane
   constexpr int SPLIT_ROLL = 64 / NSEG;   // rollouts per wave
   constexpr int NSAMP = SPLIT_SEG / 4;    // PathAlign samples per lane
-  // two segments: 32 steps per lane — the noised vy is parked in LDS next to wz.  (This instance
-  // still spills 340 bytes per lane at 256 registers, and not because of what is live: without
-  // the exact cell path's BRANCH in each of the 32 unrolled critic steps it needs 242 registers and
-  // no scratch, whatever that path computes — a division-free form, a uniform branch only, no
-  // global fetch: all tried, 332-384 bytes.  The allocator loses the plot across 32 conditional
-  // blocks.  Built and parity-tested, not selected by the host: plan_launch.)
+  // two segments: 32 steps per lane — the noised vy is parked in LDS next to wz.  (With its 32
+  // critic steps unrolled this instance spilled 340 bytes per lane at 256 registers, and not
+  // because of what is live: without the exact cell path's BRANCH in each step it needs 242
+  // registers and no scratch, whatever that path computes — a division-free form, a uniform
+  // branch only, no global fetch: all tried, 332-384 bytes; the allocator loses the plot across
+  // 32 conditional blocks.  Its critic loop is therefore ROLLED over the quads, the per-step values
+  // in register vectors read through one scalar index: 251 registers, no scratch.  Parity-green —
+  // and no faster than the lane pass (65 536 x 64: 50.0 against 49.9 us per tick): a half chain at
+  // twice the instructions per step.  Not selected by the host: plan_launch.)
   constexpr bool PARK_VY = NSEG == 2;
   const SmpcTickPtrs tk{p.u, p.px, p.py, p.pyaw, p.D, p.pf_idx, p.pvalid, p.pa_active, p.pang_active, p.pal_active};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -323,22 +333,28 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     const float yaw_off = seg_exclusive<NSEG>(ya[SPLIT_SEG - 1], r, sg);
 
     // ================= B: displacement of the segment ============================================
-    float cvx[SPLIT_SEG], cvy[PARK_VY ? 1 : SPLIT_SEG];   // parked noised controls of the lane's own steps
-    float AX[SPLIT_SEG], AY[SPLIT_SEG];     // displacement from the segment's start, inclusive
+    // Per-step values a lane keeps across the phases live in register VECTORS, element Q j + k for
+    // step 4 k + j (Q = steps per lane / 4): the rolled critic loop of the two-segment instance
+    // reads the four steps of quad k with one scalar index (s_set_gpr_idx, as smpc_lane.hip parks)
+    constexpr int Q = SPLIT_SEG / 4;
+#define SLOT(i) (Q * ((i) & 3) + ((i) >> 2))
+    typename vecN<SPLIT_SEG>::type cvx;                   // parked noised vx of the lane's own steps
+    float cvy[PARK_VY ? 1 : SPLIT_SEG];                   // ... vy (or in LDS: PARK_VY)
+    typename vecN<SPLIT_SEG>::type AX, AY;                // displacement from the segment's start, inclusive
     float vxp, vyp;                         // state velocities of the segment's first step
     {
       const float nxp = ld_prev(0), nyp = ld_prev(1);
       float ny[SPLIT_SEG];
 #pragma unroll
       for (int i = 0; i < SPLIT_SEG; ++i) {
-        cvx[i] = ld(0, i);
+        cvx[SLOT(i)] = ld(0, i);
         ny[i] = ld(1, i);
       }
       vxp = sg ? s_u[t0 - 1] + nxp : p.svx;
       vyp = sg ? s_u[64 + t0 - 1] + nyp : p.svy;
 #pragma unroll
       for (int i = 0; i < SPLIT_SEG; ++i) {
-        cvx[i] = ux_s[i] + cvx[i];
+        cvx[SLOT(i)] = ux_s[i] + cvx[SLOT(i)];
         ny[i] = uy_s[i] + ny[i];
         if constexpr (PARK_VY) park_y[i * WAVE + lane] = ny[i];
         else cvy[i] = ny[i];
@@ -350,27 +366,29 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
       float ax = 0.f, ay = 0.f;
 #pragma unroll
       for (int i = 0; i < SPLIT_SEG; ++i) {
-        const float vx = i ? cvx[i - 1] : vxp, vy = i ? ny[i - 1] : vyp;
+        const float vx = i ? cvx[SLOT(i - 1)] : vxp, vy = i ? ny[i - 1] : vyp;
         const float dxr = vx * cs_prev - vy * sn_prev;
         const float dyr = vx * sn_prev + vy * cs_prev;
         ax = ax + dxr * dt;
         ay = ay + dyr * dt;
-        AX[i] = ax;
-        AY[i] = ay;
+        AX[SLOT(i)] = ax;
+        AY[SLOT(i)] = ay;
         if (i + 1 < SPLIT_SEG) smpc_sincos((yaw_off + ya[i]) + yaw0, sn_prev, cs_prev);
       }
     }
-    const float x_off = seg_exclusive<NSEG>(AX[SPLIT_SEG - 1], r, sg);
-    const float y_off = seg_exclusive<NSEG>(AY[SPLIT_SEG - 1], r, sg);
+    const float x_off = seg_exclusive<NSEG>(AX[SLOT(SPLIT_SEG - 1)], r, sg);
+    const float y_off = seg_exclusive<NSEG>(AY[SLOT(SPLIT_SEG - 1)], r, sg);
 
     // ================= C: critics at the absolute position =======================================
     float crit = 0.f, rep = 0.f, alive = 1.0f;   // ObstaclesCritic, masked inside the segment
     float pfw = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    float sx[NSAMP], sy[NSAMP];                  // PathAlign's sample points of this lane: steps t0 + 0, 4, 8, ...
+    typename vecN<NSAMP>::type sxv, syv;         // PathAlign's sample points of this lane: steps t0 + 0, 4, 8, ...
     float x_end = 0.f, y_end = 0.f;
-#pragma unroll
-    for (int i = 0; i < SPLIT_SEG; ++i) {
-      const float axa = x_off + AX[i], aya = y_off + AY[i];
+    float vx_state = vxp;                        // state vx of the step at hand: the step before's noised control
+    // one step; i = 4 k + j with j known at compile time, k either so (unrolled) or a scalar (rolled)
+    auto step_c = [&](const int k, const int j) {
+      const int i = 4 * k + j;
+      const float axa = x_off + AX[Q * j + k], aya = y_off + AY[Q * j + k];
       // ObstaclesCritic lookup (obstacles_critic.cpp:139-171): window-relative float cell index
       // with its guard band, the exact double path for the lanes near a cell edge / outside the
       // window / off the map (smpc_lane.hip has the argument)
@@ -389,20 +407,46 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
       crit = fmaf(alive, e.crit, crit);
       rep = fmaf(alive, e.rep, rep);
       // PreferForwardCritic (prefer_forward_critic.cpp:42-46) as -dt sum min(vx, 0)
-      const float vx = i ? cvx[i - 1] : vxp;
-      pfw = pfw + fminf(vx, 0.f);
+      pfw = pfw + fminf(vx_state, 0.f);
       // gamma terms (optimizer.cpp:365-380) as sum u c - sum u^2
-      gx = fmaf(ux_s[i], cvx[i], gx);
-      gy = fmaf(uy_s[i], PARK_VY ? park_y[i * WAVE + lane] : cvy[PARK_VY ? 0 : i], gy);
+      const float cx_i = cvx[Q * j + k];
+      gx = fmaf(ux_s[i], cx_i, gx);
+      if constexpr (PARK_VY) gy = fmaf(uy_s[i], park_y[i * WAVE + lane], gy);
       gz = fmaf(uz_s[i], park[i * WAVE + lane], gz);
-      if ((i & 3) == 0) {   // PathAlign's trajectory points: every fourth step (trajectory_point_step 4)
-        sx[i >> 2] = (float)(x0 + (double)axa);
-        sy[i >> 2] = (float)(y0 + (double)aya);
+      vx_state = cx_i;
+      if (j == 0) {   // PathAlign's trajectory points: every fourth step (trajectory_point_step 4)
+        sxv[k] = (float)(x0 + (double)axa);
+        syv[k] = (float)(y0 + (double)aya);
       }
-      if (i == SPLIT_SEG - 1) {
-        x_end = (float)(x0 + (double)axa);
-        y_end = (float)(y0 + (double)aya);
+    };
+    if constexpr (NSEG == 2) {
+      // ROLLED over the quads: 32 unrolled steps, each with the exact cell path's branch, are
+      // what made this instance spill (340 bytes at 256 registers; without the branches 242 and none)
+#pragma unroll 1
+      for (int k = 0; k < Q; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) step_c(k, j);
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          step_c(k, j);
+          if constexpr (!PARK_VY) gy = fmaf(uy_s[4 * k + j], cvy[PARK_VY ? 0 : 4 * k + j], gy);
+        }
+      }
+    }
+    {
+      const float axa = x_off + AX[SLOT(SPLIT_SEG - 1)], aya = y_off + AY[SLOT(SPLIT_SEG - 1)];
+      x_end = (float)(x0 + (double)axa);
+      y_end = (float)(y0 + (double)aya);
+    }
+    float sx[NSAMP], sy[NSAMP];
+#pragma unroll
+    for (int j = 0; j < NSAMP; ++j) {
+      sx[j] = sxv[j];
+      sy[j] = syv[j];
     }
 
     // ---- ObstaclesCritic over the segments: a collision masks every later segment --------------
@@ -597,7 +641,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     {
       float V[SPLIT_SEG];
 #pragma unroll
-      for (int i = 0; i < SPLIT_SEG; ++i) V[i] = w * cvx[i];
+      for (int i = 0; i < SPLIT_SEG; ++i) V[i] = w * cvx[SLOT(i)];
       Ux = fmaf(Ux, f, row_reduce<SPLIT_SEG>(V, lane));
 #pragma unroll
       for (int i = 0; i < SPLIT_SEG; ++i) V[i] = w * (PARK_VY ? park_y[i * WAVE + lane] : cvy[PARK_VY ? 0 : i]);
