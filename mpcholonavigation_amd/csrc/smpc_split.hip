@@ -93,7 +93,6 @@ __device__ __forceinline__ float row_reduce_node(const float (&V)[N], int lane)
 // in: V[i] of every lane of a group of N lanes (a 16-lane row, or a 32-lane half); out: lane i of the group = sum over the group of V[i]
 template <int N>
 __device__ __forceinline__ float row_reduce(const float (&V)[N], int lane) {return row_reduce_node<N, 6, 0>(V, lane);}
-__device__ __forceinline__ float row_reduce16(const float (&V)[16], int lane) {return row_reduce<16>(V, lane);}
 
 // self-test of the row transpose-reduce (tests/test_gpu_parity.py): v [64 lanes][N]
 template <int N>
@@ -690,6 +689,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
   // which tick block this launch read (SmpcDev::canary_echo)
   if (p.canary_echo && !(p.flags & SD_ACCUMULATE) && blockIdx.x == 0 && tid == 0)
     p.partials[SMPC_CANARY_SLOT(T)] = tk.u[-4];
+#undef SLOT
 }
 
 extern char smpc_last_pass_kernel[96];   // smpc_kernels.hip
