@@ -616,7 +616,9 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
     bool tpr = cfg->batch_size >= kLaneMinBatch && cfg->time_steps <= kLaneMaxT;
     // (smpc_pass_split, T = 64: the time-major noise from kSplitMinBatch rollouts up; plan_launch keeps
     // the lane pass itself for batches from kLaneMinBatch up, unless it is asked for)
-    if (cfg->time_steps == 64 && cfg->batch_size >= kSplitMinBatch && !getenv("SMPC_NO_SPLIT")) tpr = true;
+    if (cfg->time_steps <= 64 && cfg->time_steps >= 36 && (cfg->time_steps & 3u) == 0 && cfg->batch_size >= kSplitMinBatch &&
+        !getenv("SMPC_NO_SPLIT"))
+      tpr = true;
     if (cfg->flags & SMPC_FLAG_WAVE_PER_ROLLOUT) tpr = false;
     if (cfg->flags & SMPC_FLAG_LANE_PER_ROLLOUT) {
       tpr = true;

@@ -101,6 +101,7 @@ inline uint32_t pass_block(int R) {return R == 4 ? 512u : 1024u;}
 constexpr uint32_t kLaneMinBatch = 60u * 1024u;   // lane-per-rollout pass from this batch size up (measured crossover ~50k: 65 536 x 64 takes 35.9 us against 40.4 us)
 constexpr uint32_t kSplitMinBatch = 12u * 1024u;  // smpc_pass_split (T = 64) from this batch size up to one group per wave (measured: 16 384 x 64
                                                   // 38.9 -> 36.2 us per tick, 32 768: 44.7 -> 36.7; 4 096: no gain)
+constexpr uint32_t kSplitMinBatchShort = 20000u;  // the same for 36 <= T < 64 (idle step slots are masked, not skipped)
 constexpr uint32_t kLaneMaxT = 128;       // T <= 64: 3 x 64 noised controls parked per lane (or re-read); T <= 128: re-read
 constexpr uint32_t kPollWords = 32;     // completion words behind h_out[3T + 8] (T = 256: 25 blocks of smpc_reduce_partials)
 constexpr uint32_t kMaxGrid = SMPC_MAX_GRID;   // smpc_reduce_partials stages this many factors

@@ -566,7 +566,8 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   // a fraction of a 64-step chain (65 536 x 64: one wave per SIMD on the lane pass).  The plain five
   // critics only; the geometry above (window, cell index constants) is shared.
   c->split_now = false;
-  if (c->lane_now && !c->lane_rr && !lane_ga && !lane_dep && mode_now == 0 && T == 64 && (gates & SD_OBSTACLES) &&
+  if (c->lane_now && !c->lane_rr && !lane_ga && !lane_dep && mode_now == 0 && T <= 64 && T >= 36 && (T & 3u) == 0 &&
+      (gates & SD_OBSTACLES) &&
       !c->in_group && !c->knob_no_split && !c->fused_reduce && (!c->lane_forced || c->knob_force_split)) {
     // (a context that ASKS for the lane pass — SMPC_FLAG_LANE_PER_ROLLOUT, SMPC_PASS=lane — gets it)
     // one block per CU (two waves per SIMD: the kernel's registers), and ONE group per wave: four
@@ -577,7 +578,11 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
     // step, 50.0 us per tick at 65 536 x 64 where the lane pass takes 49.9; SMPC_SPLIT_NSEG=2)
     uint32_t nseg = 0;
     if ((B + 15u) / 16u <= waves) nseg = 4;
+    // (horizons below 64 run the masked instance: 16 384 x 56 takes 38.0 us against 37.2 on the wave
+    // pass, 20 000 x 60 37.0 against 39.5, 32 768 x 56 39.0 against 43.5)
+    if (T != 64 && B < kSplitMinBatchShort && !c->knob_force_split) nseg = 0;
     if (c->knob_split_nseg == 2 || c->knob_split_nseg == 4) nseg = (nseg || c->knob_force_split) ? c->knob_split_nseg : 0;
+    if (nseg == 2 && T != 64) nseg = 4;   // (the two-segment instance: T = 64 only)
     if (!nseg && c->knob_force_split) nseg = 4;
     if (nseg) {
       const SmpcLds Ls = split_lds(window_bytes, P, T, nseg);

@@ -139,11 +139,15 @@ __device__ __forceinline__ float seg_total(float v)
   return v + __shfl_xor(v, 32, WAVE);
 }
 
-template <int NSEG>
+// FULL: T == 64.  Otherwise T is a multiple of four below 64 (the reference's default horizon is
+// 56): the segments keep their 64 / NSEG step slots, the slots from T on are idle — their noised
+// controls are parked as zeros, their critic terms, sample points and lookups masked (the
+// horizon's end falls into one segment; the segments behind it are idle altogether).
+template <int NSEG, bool FULL>
 __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev p, const SmpcLds L)
 {
   static_assert(NSEG == 2 || NSEG == 4, "two or four segments");
-  constexpr uint32_t T = 64;
+  const uint32_t T = FULL ? 64u : p.T;
   constexpr int SPLIT_SEG = 64 / NSEG;    // steps per lane
   constexpr int SPLIT_ROLL = 64 / NSEG;   // rollouts per wave
   constexpr int NSAMP = SPLIT_SEG / 4;    // PathAlign samples per lane
@@ -200,7 +204,9 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     const float g_px = pt_on ? tk.px[tid] : 0.f, g_py = pt_on ? tk.py[tid] : 0.f;
     const float g_D = seg_on ? tk.D[tid] : 0.f;
     const bool g_valid = seg_on && tk.pvalid[tid] != 0;
-    const float g_u = tid < 3 * 64 ? tk.u[tid] : 0.f;
+    // u [3][T] -> LDS [3][64], zeros behind the horizon
+    const uint32_t u_c = (uint32_t)tid >> 6, u_t = (uint32_t)tid & 63u;
+    const float g_u = (tid < 3 * 64 && u_t < T) ? tk.u[u_c * T + u_t] : 0.f;
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
       const int i = tid + k * blk;
@@ -232,7 +238,8 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     }
     if (tid < 3 * 64) s_u[tid] = g_u;
     if (tid < WAVE) {   // sum u^2 per control (the gamma terms as sum u c - sum u^2)
-      float a = tk.u[tid], b = tk.u[T + tid], c = tk.u[2 * T + tid];
+      const bool in = (uint32_t)tid < T;
+      float a = in ? tk.u[tid] : 0.f, b = in ? tk.u[T + tid] : 0.f, c = in ? tk.u[2 * T + tid] : 0.f;
       a *= a;
       b *= b;
       c *= c;
@@ -308,6 +315,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     const float* ux_s = s_u + t0;
     const float* uy_s = s_u + 64 + t0;
     const float* uz_s = s_u + 128 + t0;
+    auto act = [&](int i) -> bool {return FULL || t0 + (uint32_t)i < T;};   // (the same for the 16 lanes of a row)
 
     // ================= A: yaw ====================================================================
     // v[:, t] = c[:, t - 1], v[:, 0] = the measured speed (optimizer.cpp:258-267)
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
       for (int i = 0; i < SPLIT_SEG; ++i) {
         acc = acc + w * dt;
         ya[i] = acc;
-        w = uz_s[i] + nz[i];                      // NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74)
+        w = act(i) ? uz_s[i] + nz[i] : 0.f;       // NoiseGenerator::setNoisedControls (noise_generator.cpp:65-74)
         park[i * WAVE + lane] = w;                // parked for the update
       }
     }
@@ -353,8 +361,8 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
       vyp = sg ? s_u[64 + t0 - 1] + nyp : p.svy;
 #pragma unroll
       for (int i = 0; i < SPLIT_SEG; ++i) {
-        cvx[SLOT(i)] = ux_s[i] + cvx[SLOT(i)];
-        ny[i] = uy_s[i] + ny[i];
+        cvx[SLOT(i)] = act(i) ? ux_s[i] + cvx[SLOT(i)] : 0.f;
+        ny[i] = act(i) ? uy_s[i] + ny[i] : 0.f;
         if constexpr (PARK_VY) park_y[i * WAVE + lane] = ny[i];
         else cvy[i] = ny[i];
       }
@@ -401,12 +409,17 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
         if (!fast)
           idx = cell_byte_exact(p, s_map, (float)(x0 + (double)axa), (float)(y0 + (double)aya), (uint32_t)(wave * WAVE + lane));
       }
-      const SmpcLut e = s_lut[s_map[idx]];
+      SmpcLut e = s_lut[s_map[idx]];
+      const bool on_i = act(i);
+      if (!FULL) {
+        e.crit = on_i ? e.crit : 0.f;
+        e.rep = on_i ? e.rep : 0.f;
+      }
       alive = e.crit < 0.f ? 0.f : alive;    // inCollision: the rest of the segment is not visited
       crit = fmaf(alive, e.crit, crit);
       rep = fmaf(alive, e.rep, rep);
       // PreferForwardCritic (prefer_forward_critic.cpp:42-46) as -dt sum min(vx, 0)
-      pfw = pfw + fminf(vx_state, 0.f);
+      pfw = pfw + ((FULL || on_i) ? fminf(vx_state, 0.f) : 0.f);
       // gamma terms (optimizer.cpp:365-380) as sum u c - sum u^2
       const float cx_i = cvx[Q * j + k];
       gx = fmaf(ux_s[i], cx_i, gx);
@@ -436,10 +449,21 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
         }
       }
     }
-    {
+    // the endpoint, trajectory point T - 1: slot (T - 1) % (steps per lane) of segment (T - 1) / (steps per lane)
+    const uint32_t e_seg = FULL ? (uint32_t)(NSEG - 1) : (T - 1u) / (uint32_t)SPLIT_SEG;
+    if constexpr (FULL) {
       const float axa = x_off + AX[SLOT(SPLIT_SEG - 1)], aya = y_off + AY[SLOT(SPLIT_SEG - 1)];
       x_end = (float)(x0 + (double)axa);
       y_end = (float)(y0 + (double)aya);
+    } else {
+      const uint32_t e_loc = (T - 1u) % (uint32_t)SPLIT_SEG;
+#pragma unroll
+      for (int i = 3; i < SPLIT_SEG; i += 4) {   // (T a multiple of four: the last step sits in slot 3 mod 4)
+        if ((uint32_t)i == e_loc) {
+          x_end = (float)(x0 + (double)(x_off + AX[SLOT(i)]));
+          y_end = (float)(y0 + (double)(y_off + AY[SLOT(i)]));
+        }
+      }
     }
     float sx[NSAMP], sy[NSAMP];
 #pragma unroll
@@ -460,7 +484,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
       }
       crit = seg_total<NSEG>(before * crit);
       rep = seg_total<NSEG>(before * rep);
-      alive = before * alive;                 // (the last segment's lane: the whole rollout)
+      alive = before * alive;                 // (the last segment's lane: the whole rollout; idle segments leave it alone)
       alive = lane_get(alive, r + (NSEG - 1) * SPLIT_ROLL);
     }
     pfw = seg_total<NSEG>(pfw);
@@ -468,8 +492,8 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     gy = seg_total<NSEG>(gy);
     gz = seg_total<NSEG>(gz);
     // the endpoint (trajectory point T - 1) of the rollout, in its four lanes
-    x_end = lane_get(x_end, r + (NSEG - 1) * SPLIT_ROLL);
-    y_end = lane_get(y_end, r + (NSEG - 1) * SPLIT_ROLL);
+    x_end = lane_get(x_end, r + (int)e_seg * SPLIT_ROLL);
+    y_end = lane_get(y_end, r + (int)e_seg * SPLIT_ROLL);
 
     // ================= PathAlignCritic (path_align_critic.cpp:92-133) ===========================
     float pa_sum = 0.f, pa_num = 0.f;
@@ -495,7 +519,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
         }
         const float ddx = sx[j] - qx, ddy = sy[j] - qy;
         const float ch = fast_sqrt(ddx * ddx + ddy * ddy);
-        if (!(j == 0 && sg == 0)) run = run + ch;   // (step 0 is not a sample)
+        if (!(j == 0 && sg == 0) && act(4 * j)) run = run + ch;   // (step 0 is not a sample; nor are the slots behind the horizon)
         cl[j] = run;
       }
       const float d_off = seg_exclusive<NSEG>(run, r, sg);
@@ -540,6 +564,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
 #pragma unroll
         for (int j = 0; j < NSAMP; ++j) {
           if (s == 0 && j == 0) continue;   // step 0 is not a sample
+          if (!FULL && !((uint32_t)(SPLIT_SEG * s + 4 * j) < T)) continue;   // (uniform: behind the horizon)
           const uint32_t ptv = lo_j[j] == st ? 0u : cand[j];
           if (sg == s) pt_j[j] = ptv;
           st = ptv;
@@ -551,9 +576,9 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
         const f32x4 q = s_pts4[pt_j[j]];
         const float ex = q[0] - sx[j], ey = q[1] - sy[j];
         const float d = fast_sqrt(ex * ex + ey * ey);
-        const float on = (j == 0 && sg == 0) ? 0.f : q[2];   // segment valid ? 1 : 0 (path_align_critic.cpp:119-127)
+        const float on = ((j == 0 && sg == 0) || !act(4 * j)) ? 0.f : q[2];   // segment valid ? 1 : 0 (path_align_critic.cpp:119-127)
         pa_num += on;
-        pa_sum = fmaf(on, d, pa_sum);
+        pa_sum += on != 0.f ? d : 0.f;      // (a select: an idle slot's distance may be anything)
       }
       pa_num = seg_total<NSEG>(pa_num);
       pa_sum = seg_total<NSEG>(pa_sum);
@@ -661,9 +686,11 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     myp[2] = F_local;
     myp[3] = (float)n_noncoll;
   }
-  myp[4 + lane] = Ux;
-  myp[4 + T + lane] = Uy;
-  myp[4 + 2 * T + lane] = Uz;
+  if (FULL || (uint32_t)lane < T) {
+    myp[4 + lane] = Ux;
+    myp[4 + T + lane] = Uy;
+    myp[4 + 2 * T + lane] = Uz;
+  }
   __syncthreads();
   const float* allp = reinterpret_cast<const float*>(smem + L.off_scr);
   float bm = 3.0e38f;
@@ -698,11 +725,15 @@ hipError_t smpc_launch_pass_split(const SmpcDev& p, const SmpcLds& L, uint32_t g
 {
   if (nseg != 2u && nseg != 4u) return hipErrorInvalidValue;
   const uint32_t need = SD_OBSTACLES, never = SD_GOAL_ANGLE | SD_EXTRA_CRITICS | SD_STORE_TRAJ | SD_USE_PATH_YAW;
-  if (p.T != 64u || (p.flags & need) != need || (p.flags & never) || ((p.flags & SD_PATH_ALIGN) && p.step != 4u))
+  if (p.T > 64u || p.T < 20u || (p.T & 3u) || (p.flags & need) != need || (p.flags & never) ||
+      ((p.flags & SD_PATH_ALIGN) && p.step != 4u))
     return hipErrorInvalidValue;
-  snprintf(smpc_last_pass_kernel, sizeof(smpc_last_pass_kernel), "smpc_pass_split<%u>", nseg);
-  if (nseg == 4u) hipLaunchKernelGGL(smpc_pass_split<4>, dim3(grid), dim3(SPLIT_BLOCK), L.total, st, p, L);
-  else hipLaunchKernelGGL(smpc_pass_split<2>, dim3(grid), dim3(SPLIT_BLOCK), L.total, st, p, L);
+  const bool full = p.T == 64u;
+  snprintf(smpc_last_pass_kernel, sizeof(smpc_last_pass_kernel), "smpc_pass_split<%u, %s>", nseg, full ? "true" : "false");
+  if (nseg == 4u && full) hipLaunchKernelGGL((smpc_pass_split<4, true>), dim3(grid), dim3(SPLIT_BLOCK), L.total, st, p, L);
+  else if (nseg == 4u) hipLaunchKernelGGL((smpc_pass_split<4, false>), dim3(grid), dim3(SPLIT_BLOCK), L.total, st, p, L);
+  else if (full) hipLaunchKernelGGL((smpc_pass_split<2, true>), dim3(grid), dim3(SPLIT_BLOCK), L.total, st, p, L);
+  else return hipErrorInvalidValue;   // (the two-segment instance: experiments at T = 64 only)
   return hipGetLastError();
 }
 
@@ -711,14 +742,17 @@ uint32_t smpc_split_rollouts_per_block(uint32_t nseg) {return SPLIT_BLOCK / WAVE
 
 hipError_t smpc_split_occupancy(uint32_t nseg, uint32_t lds_bytes, int* blocks_per_cu)
 {
-  const void* k = nseg == 4u ? reinterpret_cast<const void*>(&smpc_pass_split<4>) : reinterpret_cast<const void*>(&smpc_pass_split<2>);
+  const void* k = nseg == 4u ? reinterpret_cast<const void*>(&smpc_pass_split<4, true>)
+                             : reinterpret_cast<const void*>(&smpc_pass_split<2, true>);
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k, SPLIT_BLOCK, lds_bytes);
 }
 
 hipError_t smpc_split_set_lds_limit(int bytes)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass_split<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass_split<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass_split<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass_split<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&smpc_pass_split<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }

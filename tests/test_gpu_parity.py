@@ -428,17 +428,20 @@ def test_row_transpose_reduce(Smpc):
         assert np.array_equal(got, want), n
 
 
-@pytest.mark.parametrize("B,M,nseg", [(16384, 200, 0), (4096, 200, 2), (65536, 200, 0), (1000, 200, 0), (16400, 2000, 0),
-                                      (70000, 200, 4), (70000, 200, 2), (32768, 200, 0)])
-def test_split_horizon_pass_parity(Smpc, Oracle, B, M, nseg, monkeypatch):
+@pytest.mark.parametrize("B,M,nseg,T", [(16384, 200, 0, 64), (4096, 200, 2, 64), (65536, 200, 0, 64), (1000, 200, 0, 64),
+                                        (16400, 2000, 0, 64), (70000, 200, 4, 64), (70000, 200, 2, 64), (32768, 200, 0, 64),
+                                        (16384, 200, 0, 56), (5000, 200, 0, 48), (3000, 200, 0, 40), (2000, 200, 0, 36),
+                                        (20000, 200, 0, 60)])
+def test_split_horizon_pass_parity(Smpc, Oracle, B, M, nseg, T, monkeypatch):
     """smpc_pass_split (lane = rollout x quarter of the horizon, the small-batch form at T = 64):
     parity with the oracle over three closed-loop ticks — the first without a furthest-point
     prediction (furthest-only pass in front), then speculated; ragged batches (tail lanes), more
-    groups than waves (70 000: forced), a costmap larger than the LDS window."""
+    groups than waves (70 000: forced), a costmap larger than the LDS window; horizons below 64
+    (the reference's default 56, and 36 .. 60: the step slots behind the horizon idle)."""
     monkeypatch.setenv("SMPC_PASS", "split")
     if nseg:
         monkeypatch.setenv("SMPC_SPLIT_NSEG", str(nseg))     # (else the library's choice: 4 lanes per rollout up to 32 768, then 2)
-    cfg, scn, noise = make_case(B, 64, map_size=M)
+    cfg, scn, noise = make_case(B, T, map_size=M)
     g, o = Smpc(cfg), Oracle(cfg)
     for obj in (g, o):
         configure(obj, scn, noise=noise)
@@ -450,9 +453,26 @@ def test_split_horizon_pass_parity(Smpc, Oracle, B, M, nseg, monkeypatch):
         uo, oo = o.optimize(tk, uo)
         assert og.pass_kind == 2, og.pass_kind
         assert og.non_colliding == oo.non_colliding
-        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"split {B} map {M} tick {k}",
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"split {B}x{T} map {M} tick {k}",
                       report=(k == 0))
         uo = np.concatenate([uo[:, 1:], uo[:, -1:]], axis=1)
+
+
+@pytest.mark.parametrize("B,T,kind", [(4096, 64, 0), (16384, 64, 2), (32768, 64, 2), (16384, 56, 0), (32768, 56, 2),
+                                      (20000, 60, 2), (32768, 30, 0), (65536, 64, 1)])
+def test_pass_chosen_by_size(Smpc, Oracle, B, T, kind):
+    """Which scoring pass a context with default flags runs (smpc_prepare.cpp plan_launch): the wave
+    pass for small batches, smpc_pass_split from 12 288 rollouts at T = 64 (20 000 at shorter
+    horizons that are multiples of four, 36 and up) while one group per wave fits, the lane pass
+    from 61 440 — and the result is the oracle's either way."""
+    cfg, scn, noise = make_case(B, T)
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, noise=noise)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert og.pass_kind == kind, (og.pass_kind, g.last_pass_kernel() if hasattr(g, "last_pass_kernel") else "")
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"chosen {B}x{T}")
 
 
 def test_windowed_furthest_scan_falls_back_exactly(Smpc, Oracle):

@@ -33,7 +33,10 @@ def block(g, scn, n):
     return (time.perf_counter() - t0) / n * 1e6, o.passes
 
 
-for B, T in ((64, 64), (2000, 56), (4096, 64), (16384, 64), (32768, 64), (65536, 64), (70000, 64), (131072, 64), (262144, 64), (2097152, 64)):
+SIZES = ((64, 64), (2000, 56), (4096, 64), (16384, 64), (32768, 64), (65536, 64), (70000, 64), (131072, 64), (262144, 64), (2097152, 64))
+if os.environ.get("TAILAB_SIZES"):      # e.g. TAILAB_SIZES=16384x56,32768x56
+    SIZES = tuple(tuple(int(v) for v in s.split("x")) for s in os.environ["TAILAB_SIZES"].split(","))
+for B, T in SIZES:
     ctxs = {k: make(B, T, e) for k, e in VARIANTS.items()}
     n = 2000 if B <= 262144 else 300
     for k, (g, scn) in ctxs.items():
