@@ -127,9 +127,27 @@ def raise_clocks(g, ms, seed=1234):
     torch.cuda.synchronize()
 
 
-def run_ticks(step_fn, scn, steps, warmup, sync, barrier, before_tick=None, after_tick=None):
+def run_ticks(step_fn, scn, steps, warmup, sync, barrier, before_tick=None, after_tick=None, compiled=None):
     """W untimed ticks, then exactly K timed ones between barrier + synchronize on both sides.
-    before_tick / after_tick (e.g. smpc_redraw_noise_async) run inside the timed region when given."""
+    before_tick / after_tick (e.g. smpc_redraw_noise_async) run inside the timed region when given.
+    compiled = (Smpc, sortham_run_ticks flags): the same W + K closed-loop ticks issued by the
+    compiled loop of host/tick_loop.cpp (one C call for the K timed ticks) instead of this
+    interpreter loop — the reference's caller is C++ (controller.cpp:80-116)."""
+    if compiled is not None:
+        from mpcholonavigation_amd import host_optimizer as H
+        g, flags = compiled
+        u = scn.u0
+        if warmup:
+            u, _ = H.run_ticks(g, scn.tick, u, warmup, flags)
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        u, outs = H.run_ticks(g, scn.tick, u, steps, flags)
+        sync()
+        barrier()
+        t1 = time.perf_counter()
+        return ((t1 - t0), sum(o.score_pass_ms for o in outs) / steps, sum(o.device_ms for o in outs) / steps,
+                sum(o.passes for o in outs) / steps, outs[steps - 1])
     u = scn.u0
     for _ in range(warmup):
         if before_tick:
@@ -238,12 +256,13 @@ def time_config(B, T, map_size, steps, warmup, flags=0, redraw=False, critics=No
     # regenerate_noises = true: the next epoch is requested behind every tick and drawn in the
     # background (smpc_redraw_noise_async: the reference's noise thread); the next tick waits for
     # it on the device, so in this back-to-back loop the whole draw is inside the timed region
-    after = g.redraw_noise_async if redraw else None
+    from mpcholonavigation_amd import host_optimizer as H
+    loop = (g, H.TICKS_SHIFT | (H.TICKS_REDRAW_ASYNC if redraw else 0))
     el, _, _, passes, out = run_ticks(g.optimize, scn, steps, warmup,
-                                      torch.cuda.synchronize, lambda: None, after_tick=after)
+                                      torch.cuda.synchronize, lambda: None, compiled=loop)
     g.set_profile(True)
     _, pass_ms, dev_ms, _, _ = run_ticks(g.optimize, scn, max(5, steps // 2), 2, torch.cuda.synchronize,
-                                         lambda: None)
+                                         lambda: None, compiled=(g, H.TICKS_SHIFT))
     P = len(scn.tick.path_x)
     by = algorithmic_bytes(B, T, map_size, map_size, P)
     tick_s = el / steps
@@ -549,29 +568,46 @@ def main():
             dist.barrier()
     else:
         step_fn = g.optimize
+        headline_kind = "single"
 
         def barrier():
             pass
 
+    # who issues the timed ticks: the compiled loop of host/tick_loop.cpp (sortham_run_ticks: the
+    # reference's caller is C++, controller.cpp:80-116) around smpc_optimize / smpc_shard_tick;
+    # the torch.distributed driver of the exchange exists in Python only.  SMPC_BENCH_CALLER=python
+    # times the interpreter loop instead (it is reported beside the headline either way).
+    from mpcholonavigation_amd import host_optimizer as H
+
+    def compiled_for(kind):
+        if kind == "torch" or os.environ.get("SMPC_BENCH_CALLER") == "python":
+            return None
+        if kind == "single":
+            return (g, H.TICKS_SHIFT)
+        return (g, H.TICKS_SHIFT | (H.TICKS_SHARD if args.no_speculate else H.TICKS_SHARD_SPECULATE))
+    loop = compiled_for(headline_kind)
+
     # the timed region: exactly K ticks, no event records in the stream
     raise_clocks(g, args.clock_warmup_ms)
     el, _, _, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
-                                      torch.cuda.synchronize, barrier)
+                                      torch.cuda.synchronize, barrier, compiled=loop)
+    # the same K ticks issued from this interpreter (Smpc.optimize + numpy shift per tick)
+    el_py = run_ticks(step_fn, scn, args.steps, 2, torch.cuda.synchronize, barrier)[0] if loop else el
     # kernel duration for the roofline: the same K ticks again with HIP events around every
     # scoring-pass launch, on the stream it is launched on (SMPC_FLAG_PROFILE; the event
     # records cost ~15 us of queue time per tick, which is why they are not in the region above)
     g.set_profile(True)
     el_prof, pass_ms, dev_ms, _, _ = run_ticks(step_fn, scn, args.steps, 2,
-                                               torch.cuda.synchronize, barrier)
+                                               torch.cuda.synchronize, barrier, compiled=loop)
     g.set_profile(False)
     # the same workload with a moving pose (closed loop; the furthest point changes as the robot
     # advances, so the speculation of a frozen scene does not flatter the tick)
     el_mv, passes_mv, mv = run_moving(step_fn, scn, cfg.model_dt, args.steps, min(args.warmup, 5),
                                       torch.cuda.synchronize, barrier)
     if sharded:
-        t = torch.tensor([el, pass_ms, el_mv], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el, pass_ms, el_mv, el_py], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, pass_ms, el_mv = float(t[0]), float(t[1]), float(t[2])
+        el, pass_ms, el_mv, el_py = float(t[0]), float(t[1]), float(t[2]), float(t[3])
 
     # N > 1: the exchange implementations that are not the headline, timed on the same workload.
     # By default only in the two-rank run: the mailbox exchange has never crossed xGMI (one-GPU
@@ -592,7 +628,7 @@ def main():
             ok, el_a, p_a = 1, 0.0, 0.0
             try:
                 el_a, _, _, p_a, _ = run_ticks(alt.optimize, scn, args.steps, args.warmup,
-                                               torch.cuda.synchronize, barrier)
+                                               torch.cuda.synchronize, barrier, compiled=compiled_for(kind))
             except Exception as e:
                 ok = 0
                 alternatives[kind] = {"error": f"rank {rank}: {e}"}
@@ -662,6 +698,15 @@ def main():
                 "device_ms_per_tick": dev_ms,
                 "timing": f"HIP events around each scoring-pass launch over {args.steps} further ticks "
                           f"({1e3 * el_prof / args.steps:.4f} ms/tick with the event records in the stream)",
+            },
+            "caller": {
+                "timed_loop": ("compiled: sortham_run_ticks (host/tick_loop.cpp) issues the W + K ticks — "
+                               + ("smpc_optimize" if headline_kind == "single" else "smpc_shard_tick")
+                               + " + shiftControlSequence per tick, as the reference's C++ controller does"
+                               if loop else "this interpreter: Smpc.optimize + numpy shift per tick"),
+                "interpreted_ms_per_step": 1e3 * el_py / args.steps,
+                "note": "interpreted_ms_per_step: the same K ticks issued from bench.py's Python loop "
+                        "(a ctypes call and two numpy allocations between ticks)",
             },
             "clock_warmup": {
                 "ms": args.clock_warmup_ms,

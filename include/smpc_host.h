@@ -71,6 +71,18 @@ int sortham_optimizer_get_optimized_trajectory(sortham_optimizer* o, float* xyya
  * history = 4 x {vx, vy, wz}, oldest first.  No GPU involved. */
 void sortham_utils_savitsky_golay(float* u, uint32_t T, float* history, int shift_control_sequence);
 
+/* n consecutive closed-loop ticks from a compiled caller: smpc_optimize (or smpc_shard_tick with
+ * SORTHAM_TICKS_SHARD*) on the same inputs, the control sequence u [3][time_steps] updated in
+ * place and, with SORTHAM_TICKS_SHIFT, shifted one step between ticks as Optimizer::evalControl
+ * does [ref src/optimizer.cpp:134-164, 206-225; the caller is src/controller.cpp:80-116].
+ * outs: n entries; *done (may be null) = ticks completed; returns the first SMPC_ERR_* met. */
+#define SORTHAM_TICKS_SHIFT 0x1u           /* shiftControlSequence after every tick            */
+#define SORTHAM_TICKS_REDRAW_ASYNC 0x2u    /* smpc_redraw_noise_async after every tick         */
+#define SORTHAM_TICKS_SHARD 0x4u           /* smpc_shard_tick(..., speculate = 0)              */
+#define SORTHAM_TICKS_SHARD_SPECULATE 0x8u /* smpc_shard_tick(..., speculate = 1)              */
+int sortham_run_ticks(smpc_ctx* ctx, const smpc_tick_in* in, float* u, uint32_t time_steps, uint32_t n,
+                      uint32_t flags, smpc_tick_out* outs, uint32_t* done);
+
 /* ---- PathHandler for plain types [ref src/path_handler.cpp:25-220, tools/path_handler.hpp:46-165]
  * Poses are {x, y, yaw} triples of doubles.  What tf2 supplies in the reference comes in as
  * arguments: the robot pose already in the plan's frame and the rigid transform

@@ -55,7 +55,11 @@ PROTOTYPES = {
     "sortham_optimizer_get_constraints": (C.c_int, [_ctx, C.c_void_p, C.POINTER(C.c_int32)]),
     "sortham_optimizer_get_optimized_trajectory": (C.c_int, [_ctx, C.c_void_p]),
     "sortham_utils_savitsky_golay": (None, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]),
+    "sortham_run_ticks": (C.c_int, [_ctx, C.POINTER(A.SmpcTickIn), C.c_void_p, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.POINTER(A.SmpcTickOut), C.POINTER(C.c_uint32)]),
 }
+
+TICKS_SHIFT, TICKS_REDRAW_ASYNC, TICKS_SHARD, TICKS_SHARD_SPECULATE = 1, 2, 4, 8
 
 DEFAULT_CRITICS = ["ObstaclesCritic", "PathAlignCritic", "PathFollowCritic", "GoalAngleCritic",
                    "PreferForwardCritic"]
@@ -72,6 +76,23 @@ def load_library():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def run_ticks(smpc, tick, u, n, flags=TICKS_SHIFT):
+    """sortham_run_ticks: n closed-loop ticks of the low-level context `smpc` (optimizer.Smpc) issued
+    by the compiled loop of host/tick_loop.cpp -> (u after the last tick [and shift], [SmpcTickOut] * n).
+    Raises SmpcError with the ticks completed in the message."""
+    lib = load_library()
+    u = np.array(u, dtype=np.float32, order="C")
+    if u.shape != (3, smpc.T):
+        raise ValueError(f"u must be [3, {smpc.T}]")
+    outs = (A.SmpcTickOut * n)()
+    done = C.c_uint32(0)
+    rc = lib.sortham_run_ticks(smpc.h, C.byref(tick.c), _ptr(u), smpc.T, n, flags, outs, C.byref(done))
+    if rc != 0:
+        from .optimizer import SmpcError
+        raise SmpcError(rc, f"after {done.value} of {n} ticks: " + (smpc.lib.smpc_last_error(smpc.h) or b"").decode())
+    return u, outs
 
 
 class Optimizer:

@@ -242,3 +242,47 @@ def test_regenerate_noises_draws_a_new_epoch_each_tick():
     # stored noise: the same inputs give the same optimize() (the Twist itself also depends
     # on the filter history, so compare the pre-filter statistics)
     assert ob2.min_cost == ob1.min_cost and ob2.sum_w == ob1.sum_w
+
+
+@pytest.mark.parametrize("regen", [False, True])
+def test_compiled_tick_loop_is_the_interpreted_loop(regen):
+    """sortham_run_ticks (host/tick_loop.cpp: what bench.py times) issues the same ticks as the
+    Python loop around smpc_optimize + shiftControlSequence: same bits, tick after tick — with the
+    device RNG's epoch drawn behind every tick as well (smpc_redraw_noise_async)."""
+    from mpcholonavigation_amd import host_optimizer as H
+    from mpcholonavigation_amd.optimizer import Smpc
+    B, T, n = 4096, 56, 6
+    scn = make_scenario(T)
+    ctxs = []
+    for _ in range(2):
+        g = Smpc(default_config(batch_size=B, time_steps=T))
+        g.set_critics(default_critics())
+        g.set_costmap(scn.cells, scn.origin_x, scn.origin_y, scn.resolution)
+        g.seed(7)
+        ctxs.append(g)
+    a, b = ctxs
+    u = scn.u0
+    outs_py = []
+    for _ in range(n):
+        u_new, out = a.optimize(scn.tick, u)
+        if regen:
+            a.redraw_noise_async()
+        outs_py.append(out)
+        u = np.concatenate([u_new[:, 1:], u_new[:, -1:]], axis=1)
+    flags = H.TICKS_SHIFT | (H.TICKS_REDRAW_ASYNC if regen else 0)
+    u_c, outs_c = H.run_ticks(b, scn.tick, scn.u0, n, flags)
+    assert np.array_equal(u_c, u)
+    for k in range(n):
+        for f in ("min_cost", "sum_w", "furthest_reached_path_point", "non_colliding", "fail_flag"):
+            assert getattr(outs_c[k], f) == getattr(outs_py[k], f), (k, f)
+    assert np.array_equal(a.get_costs(), b.get_costs())
+
+
+def test_compiled_tick_loop_reports_where_it_stopped():
+    from mpcholonavigation_amd import host_optimizer as H
+    from mpcholonavigation_amd.optimizer import Smpc, SmpcError
+    g = Smpc(default_config(batch_size=256, time_steps=56))
+    g.set_critics(default_critics())
+    scn = make_scenario(56)
+    with pytest.raises(SmpcError, match="after 0 of 3 ticks"):      # no costmap yet (SMPC_ERR_STATE)
+        H.run_ticks(g, scn.tick, scn.u0, 3)
