@@ -123,7 +123,12 @@ typedef struct smpc_config {
 typedef struct smpc_obstacles_params {
   int32_t enabled;
   int32_t consider_footprint; /* 1: SE2 footprint check near obstacles (needs
-                                 smpc_set_footprint; general pass only)         */
+                                 smpc_set_footprint; general pass only).  With
+                                 BOTH ObstaclesCritic and CostCritic in the list
+                                 and either one's consider_footprint set, the
+                                 tick is refused (SMPC_ERR_UNSUPPORTED): the two
+                                 then disagree on which rollouts collide and the
+                                 shard tuple carries one non-colliding count    */
   uint32_t cost_power;
   float repulsion_weight;
   float critical_weight;

@@ -339,7 +339,8 @@ float profile_pass_ms(smpc_ctx* c)
 // the first enabled collision critic — Constraint, Cost | Obstacles.
 uint32_t fail_only_flags(const smpc_ctx* c)
 {
-  const uint32_t coll = (c->gate_flags & SD_COST) ? SD_COST : SD_OBSTACLES;
+  // (with its consider_footprint switch: the re-score has to find the same collisions)
+  const uint32_t coll = (c->gate_flags & SD_COST) ? (SD_COST | SD_FP_COST) : (SD_OBSTACLES | SD_FP_OBSTACLES);
   return c->gate_flags & (SD_CONSTRAINT | coll | SD_STORE_TRAJ | SD_TRACK_UNKNOWN);
 }
 

@@ -895,8 +895,9 @@ __global__ void __launch_bounds__((R == 4 ? 512 : 1024), (R == 4 ? 2 : 4)) smpc_
           const float v = (p.obs_critical_w * raw) + (p.obs_repulsion_w * rep_sum / (float)T);
           cost = add_cost_pow(cost, (double)v, p.obs_power);
         } else {
-          lin = (collided ? 0.f : obs_cw * crit) + obs_rt * rep;
-          uni = collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
+          // (added, not assigned: with CostCritic in the list too its terms are already in here)
+          lin += (collided ? 0.f : obs_cw * crit) + obs_rt * rep;
+          uni += collided ? p.obs_critical_w * p.obs_collision_cost : 0.f;
         }
       }
     }

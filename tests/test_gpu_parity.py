@@ -776,6 +776,61 @@ def test_consider_footprint_needs_a_footprint(Smpc):
         g.optimize(scn.tick, scn.u0)
 
 
+@pytest.mark.parametrize("fp_critic,names", [("obstacles", ("obstacles", "path_follow", "prefer_forward")),
+                                             ("cost", ("constraint", "cost", "path_follow", "goal"))])
+def test_all_collide_with_a_footprint_is_rescored_with_the_footprint(Smpc, Oracle, fp_critic, names):
+    """Every rollout collides only because of the FOOTPRINT (a lethal wall 0.2 m ahead: under the
+    outline at the common first pose, never under a centre that stays or backs off): the tick fails,
+    and the re-score that restates what the reference had scored when its manager stopped
+    (critic_manager.cpp:70-73) must find the same collisions — it once dropped the
+    consider_footprint switch and let the rollouts whose centres stay clear survive.  (Found by
+    tools/fuzz_parity.py.)"""
+    B, T = 512, 20
+    cfg, scn, noise = make_case(B, T)
+    res, t = scn.resolution, scn.tick
+    cx, cy = int(t.pose_x / res), int(t.pose_y / res)
+    cells = np.zeros_like(scn.cells)
+    cells[cy - 30:cy + 30, cx - 6:cx + 4] = 100          # above the possibly-inscribed cost: footprint checked
+    cells[cy - 30:cy + 30, cx + 4] = 254
+    scn.cells = cells
+    scn.tick = Tick(t.pose_x, t.pose_y, 0.0, (0.0, 0.0, 0.0), t.path_x, t.path_y, t.path_yaw, t.goal_x, t.goal_y)
+    u0 = np.zeros_like(scn.u0)
+    u0[0] = -0.2                                          # backing off: most centres never reach the wall
+    cr = _extra_critics(names)
+    getattr(cr, fp_critic).consider_footprint = 1
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, critics=cr, noise=noise)
+        obj.set_footprint(FOOTPRINT, circumscribed_radius=float(np.hypot(0.25, 0.18)), layer_cost_scaling_factor=10.0)
+    ug, og = g.optimize(scn.tick, u0)
+    uo, oo = o.optimize(scn.tick, u0)
+    assert oo.fail_flag == 1 and oo.non_colliding == 0
+    assert og.fail_flag == 1 and og.non_colliding == 0
+    cg, co = g.get_costs(), o.get_costs()
+    assert np.max(np.abs(cg.astype(np.float64) - co)) <= 2e-6 * float(np.max(np.abs(co))), (cg[:4], co[:4])
+    # without the footprint the same tick does not fail: the footprint is what decides it
+    getattr(cr, fp_critic).consider_footprint = 0
+    o.set_critics(cr)
+    _, o2 = o.optimize(scn.tick, u0)
+    assert o2.fail_flag == 0 and o2.non_colliding > 0
+
+
+@pytest.mark.parametrize("B,T", [(400, 100), (3000, 56), (20000, 64)])
+def test_cost_and_obstacles_critics_together(Smpc, Oracle, B, T):
+    """Both collision critics in the list, every cost_power 1 (the additive fast forms of MODE 3):
+    ObstaclesCritic's terms are ADDED to CostCritic's — they once replaced them (found by
+    tools/fuzz_parity.py: 263 of 400 costs off by up to 4 %)."""
+    cfg, scn, noise = make_case(B, T)
+    cr = _extra_critics(("obstacles", "cost", "path_follow", "prefer_forward", "constraint"))
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, critics=cr, noise=noise)
+    ug, og = g.optimize(scn.tick, scn.u0)
+    uo, oo = o.optimize(scn.tick, scn.u0)
+    assert og.non_colliding == oo.non_colliding
+    assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"cost + obstacles {B}x{T}")
+
+
 FIVE = ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward")
 
 
