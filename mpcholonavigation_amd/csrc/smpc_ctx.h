@@ -70,8 +70,7 @@ hipError_t smpc_split_occupancy(uint32_t nseg, uint32_t lds_bytes, int* blocks_p
 hipError_t smpc_split_set_lds_limit(int bytes);
 hipError_t smpc_launch_pass_lane_many(const SmpcDev* d_many, uint32_t n, bool full, bool obst, bool dep, uint32_t T,
                                       const SmpcLds& L, uint32_t grid, uint32_t block, hipStream_t st);
-hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
-                                   float neg_inv_temp, hipStream_t st);
+hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T, hipStream_t st);
 // developer aid: the scoring-pass instance launched last, as rocprofv3 names it
 extern char smpc_last_pass_kernel[96];
 hipError_t smpc_launch_sincos(const float* x, uint32_t n, float* sn, float* cs, hipStream_t st);

@@ -257,6 +257,7 @@ struct SmpcReduceArgs {
   SmpcFinal fin;       // u_host and done_counter null: smpc_publish_many reports to the host
   float* host_out;     // the instance's host-mapped result mirror [3T + 8]
   uint32_t seq;        // sequence number published at host_out[3T + 7]
+  float neg_inv_temp;  // -1 / temperature of THIS instance (members of a group may differ)
 };
 
 // LDS carve-up, computed once on the host and passed to the kernel.

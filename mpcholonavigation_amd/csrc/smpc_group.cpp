@@ -163,6 +163,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     hr[i].nblk = gridx;
     hr[i].host_out = fin.u_host;
     hr[i].seq = fin.seq;
+    hr[i].neg_inv_temp = c->dev.neg_inv_temp;   // (its own: the members share the horizon, nothing else)
     fin.u_host = nullptr;          // one publishing block for the whole group instead
     fin.done_counter = nullptr;
     hr[i].fin = fin;
@@ -181,7 +182,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
   HIPCK(c0, smpc_launch_pass_lane_many(reinterpret_cast<const SmpcDev*>(g->d_all + g->off_dev), n,
                                        T == 64, obst, dep, T, L, gridx, c0->lane_block, g->stream));
   HIPCK(c0, smpc_launch_reduce_many(reinterpret_cast<const SmpcReduceArgs*>(g->d_all + g->off_red), n,
-                                    T, c0->dev.neg_inv_temp, g->stream));
+                                    T, g->stream));
   g->batched_ticks++;
   const auto t_launch = now();
   // ---- per member: wait, verify the speculation and the collision count --------------------

@@ -1294,10 +1294,10 @@ __global__ void __launch_bounds__(1024) smpc_reduce_partials(const float* __rest
 
 // several planning instances in one launch (smpc_group_optimize): blockIdx.y picks the instance
 __global__ void __launch_bounds__(1024) smpc_reduce_partials_many(const SmpcReduceArgs* __restrict__ many,
-                                                                 uint32_t T, float neg_inv_temp)
+                                                                 uint32_t T)
 {
   const SmpcReduceArgs& a = many[blockIdx.y];
-  reduce_partials_body(a.partials, a.nblk, T, neg_inv_temp, a.tuple, a.fin);
+  reduce_partials_body(a.partials, a.nblk, T, a.neg_inv_temp, a.tuple, a.fin);
 }
 
 // ---------------------------------------------------------------------------
@@ -1691,12 +1691,10 @@ __global__ void __launch_bounds__(1024) smpc_publish_many(const SmpcReduceArgs* 
                        __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T,
-                                   float neg_inv_temp, hipStream_t st)
+hipError_t smpc_launch_reduce_many(const SmpcReduceArgs* d_many, uint32_t n, uint32_t T, hipStream_t st)
 {
   const uint32_t TL = 4 + 3 * T;
-  hipLaunchKernelGGL(smpc_reduce_partials_many, dim3((TL + 31) / 32, n), dim3(1024), 0, st, d_many, T,
-                     neg_inv_temp);
+  hipLaunchKernelGGL(smpc_reduce_partials_many, dim3((TL + 31) / 32, n), dim3(1024), 0, st, d_many, T);
   hipLaunchKernelGGL(smpc_publish_many, dim3(1), dim3(1024), 0, st, d_many, n, T);
   return hipGetLastError();
 }

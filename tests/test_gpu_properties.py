@@ -365,6 +365,58 @@ def test_grouped_contexts_tick_in_one_launch():
         g.close()
 
 
+def test_grouped_contexts_keep_their_own_temperature():
+    """Members of a group share the horizon and nothing else: each member's partials are reduced with
+    ITS temperature (the batched reduction once used the first member's for all of them: sum_w 3.72
+    for 2.00, the control sequence off by 0.37 — found by tools/fuzz_group.py)."""
+    from mpcholonavigation_amd.optimizer import Smpc, SmpcGroup
+    from tests.helpers import configure
+    B, T = 2048, 56
+    temps = (1.0, 0.1, 0.3, 0.05)
+    cases = []
+    for i, temp in enumerate(temps):
+        cfg = default_config(batch_size=B, time_steps=T, flags=A.SMPC_FLAG_LANE_PER_ROLLOUT, temperature=temp,
+                             gamma=0.015 * (i + 1))
+        scn = make_scenario(T, seed=70 + i)
+        cases.append((cfg, scn, make_noise(B, T, seed=950 + i)))
+
+    def fresh():
+        out = []
+        for cfg, scn, noise in cases:
+            g = Smpc(cfg)
+            configure(g, scn, noise=noise)
+            out.append(g)
+        return out
+
+    os.environ["SMPC_NO_HALF_BLOCKS"] = "1"      # (as above: the same block size alone and grouped)
+    try:
+        alone = fresh()
+    finally:
+        del os.environ["SMPC_NO_HALF_BLOCKS"]
+    grouped = fresh()
+    grp = SmpcGroup(grouped)
+    us = [scn.u0 for _, scn, _ in cases]
+    batched = 0
+    for k in range(4):
+        ticks = []
+        for cfg, scn, noise in cases:
+            t = scn.tick
+            ticks.append(Tick(t.pose_x + 0.02 * k, t.pose_y, t.pose_yaw, (0.3, 0.0, 0.0), t.path_x, t.path_y, t.path_yaw,
+                              t.goal_x, t.goal_y))
+        res = grp.optimize(ticks, us)
+        for i in range(len(cases)):
+            ua, oa = alone[i].optimize(ticks[i], us[i])
+            ug, og = res[i]
+            assert oa.sum_w == og.sum_w and oa.min_cost == og.min_cost, (k, i, temps[i], oa.sum_w, og.sum_w)
+            assert np.array_equal(ua, ug), (k, i, temps[i])
+            batched += og.passes == 1
+            us[i] = np.concatenate([ua[:, 1:], ua[:, -1:]], axis=1)
+    assert batched >= 8          # the batched launch really ran (first tick and prediction misses aside)
+    grp.close()
+    for g in alone + grouped:
+        g.close()
+
+
 def test_grouped_contexts_with_the_deployed_critic_list():
     """A fleet whose members score the reference's deployed critic list (Constraint / Cost /
     Twirling next to the path critics): the batched launch of smpc_group_optimize has the lane

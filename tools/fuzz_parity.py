@@ -76,10 +76,18 @@ def draw(case):
     d["limit"] = float(r.choice([0.0, 0.0, 0.0, 0.5, 0.8]))            # constraints scaled before tick 1 (setSpeedLimit)
     d["map_edit"] = bool(r.random() < 0.2)                             # a block of the costmap changes before tick 2
     d["lethal_blob"] = bool(r.random() < 0.1)                          # lethal cells right in front of the robot
+    d["res"] = float(r.choice([0.05, 0.05, 0.05, 0.1, 0.025]))         # costmap resolution (the scene scales with it)
+    d["origin"] = (float(r.choice([0.0, 0.0, -3.7, 12.25])), float(r.choice([0.0, 0.0, 5.5, -1.05])))
+    d["crop"] = (int(r.choice([0, 0, 1, 3, 17])), int(r.choice([0, 0, 2, 5])))   # columns / rows cut off the map
+    d["pa_step"] = int(r.choice([4, 4, 4, 2, 3, 5, 8]))               # PathAlign trajectory_point_step
+    d["occupied_path"] = float(r.choice([0.0, 0.0, 0.0, 0.05, 0.3]))   # share of the plan's points put on lethal cells
+    d["big"] = bool(r.random() < 0.004)                                # a batch the lane pass takes by itself
     return d
 
 
 def build(d):
+    if d.get("big"):
+        d["B"] = 70001 if d["T"] <= 64 else 66000
     cfg = default_config(batch_size=d["B"], time_steps=d["T"], iteration_count=d["iters"], motion_model=d["model"],
                          model_dt=d["dt"], temperature=d["temperature"], gamma=d["gamma"], flags=d["flags"])
     if d["model"] != A.SMPC_MODEL_OMNI:
@@ -132,6 +140,28 @@ def build(d):
     if d["edge"]:
         tick.pose_x = float(W - 0.3)
         tick.pose_y = float(min(max(tick.pose_y, 0.3), W - 0.3))
+    if d["occupied_path"] > 0.0:
+        scn.cells = scn.cells.copy()
+        for i in np.nonzero(r.random(len(tick.path_x)) < d["occupied_path"])[0]:
+            if i > 6:      # (not under the robot)
+                scn.cells[min(int(tick.path_y[i] / scn.resolution), d["map"] - 1), min(int(tick.path_x[i] / scn.resolution), d["map"] - 1)] = 254
+    cr.path_align.trajectory_point_step = d["pa_step"]
+    cr.path_align_legacy.trajectory_point_step = d["pa_step"]
+    # columns / rows cut off (odd widths: the LDS staging's byte path), then the scene scaled to the
+    # resolution and moved to the origin
+    cw, ch = d["crop"]
+    if cw or ch:
+        scn.cells = np.ascontiguousarray(scn.cells[:scn.cells.shape[0] - ch, :scn.cells.shape[1] - cw])
+    k = d["res"] / scn.resolution
+    ox, oy = d["origin"]
+    if k != 1.0 or ox != 0.0 or oy != 0.0:
+        scn.resolution = d["res"]
+        scn.origin_x, scn.origin_y = ox, oy
+        tick = Tick(pose_x=ox + k * tick.pose_x, pose_y=oy + k * tick.pose_y, pose_yaw=tick.pose_yaw, speed=tick.speed,
+                    path_x=(ox + k * tick.path_x.astype(np.float64)).astype(np.float32),
+                    path_y=(oy + k * tick.path_y.astype(np.float64)).astype(np.float32), path_yaw=tick.path_yaw,
+                    goal_x=float(np.float32(ox + k * tick.goal_x)), goal_y=float(np.float32(oy + k * tick.goal_y)),
+                    goal_checker_xy_tolerance=tick.goal_checker_xy_tolerance)
     if d["footprint"] and "obstacles" in d["critics"] and "cost" in d["critics"]:
         d["footprint"] = ""      # refused by the library (SMPC_ERR_UNSUPPORTED): both collision critics with a footprint
     if d["footprint"]:
@@ -197,7 +227,9 @@ def check(case, k, d, ug, og, uo, oo, cg, co):
     # float32 costs carry ~8 ulps of summation noise whatever the order; the softmax turns an ulp of
     # the minimum cost into ulp / temperature on a weight
     cond = 32.0 * float(np.spacing(np.float32(abs(oo.min_cost) + 1.0))) / d["temperature"]
-    if err > (1e-4 + cond) * float(np.max(np.abs(tr))) + 2e-6:
+    # (... and the Twist is a weighted mean of NOISE: its error scales with the sampling std, 0.2 - 0.4,
+    # not with its own size)
+    if err > (1e-4 + cond) * float(np.max(np.abs(tr))) + 2e-6 + 0.1 * cond:
         if d["temperature"] < 0.3 and e <= 1e-3 and not (hard or soft):
             # costs agree to a few 1e-6 relative (float sums in another order); at temperature 0.1 with
             # two or three rollouts carrying the weight that is 1e-4 on the Twist
@@ -246,7 +278,8 @@ def run(case):
                     obj.set_constraints(cfg.vx_max * f, cfg.vx_min * f, cfg.vy_max * f, cfg.wz_max * f)
             if k == 2 and d["map_edit"]:
                 cells = cells.copy()
-                cy, cx = int(tick.pose_y / scn.resolution), int(tick.pose_x / scn.resolution)
+                cy, cx = int((tick.pose_y - scn.origin_y) / scn.resolution), int((tick.pose_x - scn.origin_x) / scn.resolution)
+                cy, cx = min(max(cy, 0), cells.shape[0] - 1), min(max(cx, 0), cells.shape[1] - 1)
                 cells[max(cy - 20, 0):cy + 20, cx + 5:cx + 30] = np.roll(cells[max(cy - 20, 0):cy + 20, cx + 5:cx + 30], 3, axis=0)
                 for obj in (g, o):
                     obj.set_costmap(cells, scn.origin_x, scn.origin_y, scn.resolution, track_unknown=d["track_unknown"],
@@ -293,11 +326,13 @@ def main():
             print(f"case {case}: ok{' (' + '; '.join(notes) + ')' if notes else ''}  B {d['B']} T {d['T']} model {d['model']} it {d['iters']} flags {d['flags']:#x} "
                   f"pass {d['env_pass'] or '-'} kinds {kinds} critics {d['critic_kind']} map {d['map']} "
                   f"{'fp:' + d['footprint'] + ' ' if d['footprint'] else ''}{'unk ' if d['unknown'] else ''}{'rng ' if d['rng'] else ''}"
-                  f"{'edge ' if d['edge'] else ''}{'limit ' if d['limit'] else ''}{'edit ' if d['map_edit'] else ''}{'blob ' if d['lethal_blob'] else ''}"
+                  f"{'res %g ' % d['res'] if d['res'] != 0.05 else ''}{'big ' if d['big'] else ''}{'edge ' if d['edge'] else ''}{'limit ' if d['limit'] else ''}{'edit ' if d['map_edit'] else ''}{'blob ' if d['lethal_blob'] else ''}"
                   f"({time.time() - t0:.0f} s)", flush=True)
         except Exception as e:
-            bad += 1
             msg = str(e).splitlines()[0] if str(e) else type(e).__name__
+            if "more than 63 samples per trajectory" in msg:      # a documented refusal (SMPC_ERR_UNSUPPORTED)
+                continue
+            bad += 1
             print(f"case {case}: FAILED  {type(e).__name__}: {msg[:300]}\n    draw: {draw(case)}", flush=True)
             if only:
                 traceback.print_exc()
