@@ -24,6 +24,8 @@ from mpcholonavigation_amd.tick import Tick, default_config, default_critics
 from oracle.loader import Oracle
 from tests.helpers import assert_parity, configure
 
+default_config = default_config   # (re-exported for the other fuzz tools)
+
 CRITICS = ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward", "cost", "goal",
            "constraint", "twirling", "path_angle", "velocity_deadband", "path_align_legacy")
 
