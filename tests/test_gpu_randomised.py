@@ -1,5 +1,5 @@
 """A bounded, seeded slice of the randomised sweeps under tools/ (fuzz_parity.py, fuzz_group.py,
-fuzz_shards.py, fuzz_host.py) as part of the GPU suite: random configurations, critic lists with
+fuzz_shards.py, fuzz_host.py, fuzz_state.py) as part of the GPU suite: random configurations, critic lists with
 perturbed parameters, scenes (resolution, origin, odd map sizes, unknown cells, plans that curve,
 robots at the map's edge), three closed-loop ticks each, library against oracle.  The full sweeps
 (tens of thousands of cases, minutes on one GPU) found three defects that the hand-written cases had
@@ -52,3 +52,11 @@ def test_randomised_shards():
 def test_randomised_host_closed_loops():
     H = _tool("fuzz_host")
     _sweep(H.run, range(0, 120))
+
+
+def test_randomised_call_sequences():
+    """tools/fuzz_state.py: one long-lived context, 24 calls each — ticks with a moving pose, new
+    plans, costmaps and costmap regions, critic parameters, speed limits, reset, stored noise, the
+    device RNG and its epochs in the foreground and behind a tick."""
+    S = _tool("fuzz_state")
+    _sweep(lambda case: S.run(case), range(0, 100))
