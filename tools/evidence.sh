@@ -30,6 +30,24 @@ for C in FETCH_SIZE WRITE_SIZE; do
   find "$OUT/pmc_$C" -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} "$OUT/pmc_${C}_2097152x64.csv"
 done
 python3 $ROOT/tools/make_traffic_json.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" 2097152 64 200x200 "$OUT/traffic_2097152x64.json" > /dev/null
+# 3b. the VALU budget of the headline's lane pass and of the split pass (one PMC pass each, no trace domains)
+for SPEC in "lane_2097152x64 2097152 64" "split_32768x64 32768 64" "lane_65536x64 65536 64"; do
+  set -- $SPEC
+  rm -rf "$OUT/pmc_sq"
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+    --output-format csv -d "$OUT/pmc_sq" -- python3 $ROOT/tools/config_ticks.py $2 $3 200 40 > "$OUT/pmc_sq_$1.stdout" 2>&1
+  python3 $ROOT/tools/pmc_summary.py "$OUT/pmc_sq" $2 $3 > "$OUT/pmc_SQ_$1.txt" 2>&1
+done
+rm -rf "$OUT/pmc_sq"
+# 3c. who issues the ticks, and the split pass against the wave pass (same call, same box)
+python3 $ROOT/tools/caller_ab.py 2000x56 65536x64 262144x64 2097152x64 > "$OUT/ab_caller_python_vs_compiled.txt" 2>&1
+python3 $ROOT/tools/tail_ab.py SMPC_NO_SPLIT=1 > "$OUT/ab_split_pass_by_batch.txt" 2>&1
+TAILAB_SIZES=12288x56,16384x56,20000x60,32768x56,32768x48 python3 $ROOT/tools/tail_ab.py SMPC_NO_SPLIT=1 > "$OUT/ab_split_pass_short_horizons.txt" 2>&1
+# 3d. the N > 1 code path of bench.py with two processes on this one GPU (RCCL refuses that: the torch/gloo driver
+# carries the headline, the mailbox exchange beside it), then with the stand-in for the nccl* symbols
+( export SMPC_BENCH_SHARE_GPU=1 SMPC_BENCH_BACKEND=gloo
+  python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $ROOT/bench.py --gpus 2 --steps 20 --warmup 3 --total-rollouts 131072 > "$OUT/bench_2ranks_one_gpu_rehearsal.json" 2> "$OUT/bench_2ranks.stderr"
+  SMPC_RCCL_LIB=$ROOT/tests/fake_rccl/libfake_rccl.so python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 $ROOT/bench.py --gpus 2 --steps 20 --warmup 3 --total-rollouts 131072 > "$OUT/bench_2ranks_one_gpu_standin_rehearsal.json" 2> "$OUT/bench_2ranks_standin.stderr" )
 # 4. where a tick's fixed cost goes
 : > "$OUT/tick_timeline.txt"
 for BT in "2000 56" "65536 64" "262144 64"; do
