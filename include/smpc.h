@@ -126,9 +126,11 @@ typedef struct smpc_obstacles_params {
                                  smpc_set_footprint; general pass only).  With
                                  BOTH ObstaclesCritic and CostCritic in the list
                                  and either one's consider_footprint set, the
-                                 tick is refused (SMPC_ERR_UNSUPPORTED): the two
-                                 then disagree on which rollouts collide and the
-                                 shard tuple carries one non-colliding count    */
+                                 two disagree on which rollouts collide and a
+                                 shard tuple carries one non-colliding count:
+                                 smpc_optimize scores such a tick with an extra
+                                 counting pass, the sharded tick
+                                 (smpc_shard_*) refuses it (SMPC_ERR_UNSUPPORTED) */
   uint32_t cost_power;
   float repulsion_weight;
   float critical_weight;

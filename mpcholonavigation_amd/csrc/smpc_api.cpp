@@ -94,7 +94,7 @@ void free_ctx(smpc_ctx* c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (float* p : {c->d_tvx, c->d_nvx, c->d_nvy, c->d_nwz, c->d_costs[0], c->d_costs[1], c->d_traj[0],
-         c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_furthest})
+         c->d_traj[1], c->d_traj[2], c->d_partials, c->d_tuple, c->d_out, c->d_u_iter, c->d_furthest})
     if (p) (void)hipFree(p);
   if (c->fill_stream) {
     (void)hipStreamSynchronize(c->fill_stream);
@@ -638,6 +638,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
       }
     }
     c->knob_no_split = getenv("SMPC_NO_SPLIT") != nullptr;
+    c->knob_repeat_pass = getenv("SMPC_DEBUG_REPEAT_PASS") != nullptr;
     if (const char* e = getenv("SMPC_SPLIT_NSEG")) c->knob_split_nseg = static_cast<uint32_t>(std::max(0, atoi(e)));
     if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) tpr = false;   // visualisation path: wave pass
     if (3ull * n >= (1ull << 32)) tpr = false;   // its buffer descriptor spans the three noise tensors
@@ -675,6 +676,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
   CK(hipMemset(c->d_partials, 0, (kMaxGrid * TL + 16) * sizeof(float)));
   CK(hipMalloc(&c->d_tuple, TL * sizeof(float)));
   CK(hipMalloc(&c->d_out, (3 * T + 8) * sizeof(float)));
+  CK(hipMalloc(&c->d_u_iter, 3 * T * sizeof(float)));
   // [3T + 8 ...]: completion words, one per publishing block (at most 13: T = 128)
   CK(hipHostMalloc(&c->h_out, (3 * T + 8 + kPollWords) * sizeof(float), hipHostMallocMapped));
   memset(c->h_out, 0, (3 * T + 8 + kPollWords) * sizeof(float));
@@ -950,11 +952,21 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
   bool S_known = false, S_on_device = false;
   uint32_t S_host = 0;
   float F_host = 0.f;
+  bool have_nc_obstacles = false;   // (two_coll_fp: ObstaclesCritic's own non-colliding count, the last one assigned)
+  float nc_obstacles = 0.f;
   const bool speculate = !(c->cfg.flags & SMPC_FLAG_NO_SPECULATION);
   for (uint32_t it = 0; it < c->cfg.iteration_count; ++it) {
     uint32_t flags = scoring_flags(c, fail_sticky);
     if (it > 0) flags |= SD_ACCUMULATE;
-    const float* u_dev = it == 0 ? nullptr : c->d_out;
+    // a later iteration starts from what the previous one left in d_out — from a COPY of it: the
+    // reduction of this iteration's first pass overwrites d_out, and a second pass of the same
+    // iteration (speculation miss, all-collide re-score, the counting pass below) has to read
+    // the same control sequence as the first
+    const float* u_dev = nullptr;
+    if (it > 0) {
+      HIPCK(c, hipMemcpyAsync(c->d_u_iter, c->d_out, 3 * T * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      u_dev = c->d_u_iter;
+    }
     c->costs_cur = it & 1;
     const float* dF = nullptr;
     uint32_t hintS = 0;
@@ -1011,7 +1023,44 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
         if (rc != SMPC_OK) return rc;
       }
     }
-    if ((flags & (SD_OBSTACLES | SD_COST)) && c->h_out[iNC] == 0.0f) {
+    if (c->knob_repeat_pass) {   // (tests: a second pass of the iteration must see the first one's inputs)
+      rc = launch_score(c, flags & ~SD_LOCAL_FURTHEST, u_dev, nullptr, S_known ? S_host : hintS, c->d_tuple, true, nullptr);
+      if (rc != SMPC_OK) return rc;
+      rc = fetch_out(c);
+      if (rc != SMPC_OK) return rc;
+      fetched = true;
+    }
+    bool failed_at_obstacles = false;
+    if (c->two_coll_fp && (flags & SD_OBSTACLES) && (flags & SD_COST) && c->h_out[iNC] != 0.0f) {
+      // CostCritic (scored first, its count is the one the pass reports) let some rollouts
+      // through; ObstaclesCritic is scored next and, with a footprint in play, decides on its OWN
+      // collisions (obstacles_critic.cpp:177 assigns fail_flag).  One pass that scores it alone
+      // counts them; then either the manager stopped behind it (critic_manager.cpp:70-73:
+      // Constraint, Cost, Obstacles were scored) or everything is scored again.
+      const uint32_t acc = it > 0 ? SD_ACCUMULATE : 0u;
+      const uint32_t keep = SD_STORE_TRAJ | SD_TRACK_UNKNOWN;
+      rc = launch_score(c, (c->gate_flags & (SD_OBSTACLES | SD_FP_OBSTACLES | keep)) | acc, u_dev, nullptr, 0,
+                        c->d_tuple, true, nullptr);
+      if (rc != SMPC_OK) return rc;
+      rc = fetch_out(c);
+      if (rc != SMPC_OK) return rc;
+      nc_obstacles = c->h_out[iNC];
+      uint32_t again = flags & ~SD_LOCAL_FURTHEST;
+      if (nc_obstacles == 0.0f) {
+        failed_at_obstacles = true;
+        fail_flag = true;
+        fail_sticky = true;
+        again = (c->gate_flags & (SD_CONSTRAINT | SD_COST | SD_FP_COST | SD_OBSTACLES | SD_FP_OBSTACLES | keep)) | acc;
+      }
+      rc = launch_score(c, again, u_dev, nullptr, S_known ? S_host : 0u, c->d_tuple, true, nullptr);
+      if (rc != SMPC_OK) return rc;
+      if (c->cfg.flags & SMPC_FLAG_PROFILE) HIPCK(c, hipEventRecord(c->ev1, c->stream));
+      rc = fetch_out(c);
+      if (rc != SMPC_OK) return rc;
+      fetched = true;
+      have_nc_obstacles = true;
+    }
+    if (!failed_at_obstacles && (flags & (SD_OBSTACLES | SD_COST)) && c->h_out[iNC] == 0.0f) {
       // every rollout collides: the critics after Obstacles were not scored in the
       // reference (critic_manager.cpp:70-73); redo this iteration with Obstacles only
       // so that costs and u match it exactly
@@ -1036,7 +1085,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
     out->fail_flag = fail_flag ? 1 : 0;
     out->furthest_valid = S_known ? 1 : 0;
     out->furthest_reached_path_point = S_known ? S_host : 0;
-    out->non_colliding = static_cast<uint32_t>(c->h_out[iNC]);
+    out->non_colliding = static_cast<uint32_t>(have_nc_obstacles ? nc_obstacles : c->h_out[iNC]);
     out->min_cost = c->h_out[3 * T + 0];
     out->sum_w = c->h_out[3 * T + 1];
     out->passes = c->passes;

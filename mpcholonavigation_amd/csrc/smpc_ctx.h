@@ -186,6 +186,9 @@ struct smpc_ctx {
   uint32_t knob_split_nseg = 0;          // SMPC_SPLIT_NSEG=2|4: experiments
   bool lane_forced = false;              // SMPC_FLAG_LANE_PER_ROLLOUT / SMPC_PASS=lane|split: the lane pass below kLaneMinBatch too
   bool knob_no_split = false;            // SMPC_NO_SPLIT=1
+  bool knob_repeat_pass = false;         // SMPC_DEBUG_REPEAT_PASS=1 (tests): every iteration's scoring pass is launched twice
+  bool two_coll_fp = false;              // this tick: BOTH collision critics scored and a consider_footprint switch set —
+                                         // they then disagree on which rollouts collide (smpc_optimize: a counting pass)
   bool knob_force_split = false;         // SMPC_PASS=split: wherever the instance applies, whatever the batch
   bool lane_rr = false;      // ... in its re-read form (no parked controls; T > 64 or SMPC_LANE_REREAD=1)
   uint32_t last_pass_kind = 0;
@@ -256,6 +259,8 @@ struct smpc_ctx {
   float* d_partials = nullptr;
   float* d_tuple = nullptr;
   float* d_out = nullptr;       // [3T u][8 result]
+  float* d_u_iter = nullptr;    // [3T] the control sequence iteration it > 0 starts from: a copy of d_out, so that a
+                                // second pass of the same iteration (a re-score) reads what the first one read
   float* h_out = nullptr;       // pinned, device-mapped: kernels write the result here
   float* h_out_dev = nullptr;   // its device-side address
   bool fused_reduce = false;    // SMPC_FUSED_REDUCE=1: smpc_grid_tail reduces inside the scoring launch (an experiment

@@ -128,7 +128,7 @@ int smpc_group_optimize(smpc_group* g, const smpc_tick_in* ins, float* const* u_
     const bool ok = c->lane_now && !c->lane_rr && !(flags[i] & SD_GOAL_ANGLE) &&
       c->cfg.iteration_count == 1 && !c->fail_in &&
       !(c->cfg.flags & (SMPC_FLAG_NO_SPECULATION | SMPC_FLAG_PROFILE)) && (!need_f || c->hint_valid) &&
-      c->poll_enabled && c->acker_r < 0.f;
+      c->poll_enabled && c->acker_r < 0.f && !c->two_coll_fp;
     if (!ok) batched = false;
     if (i == 0) {
       window_bytes = c->lane_window_bytes;

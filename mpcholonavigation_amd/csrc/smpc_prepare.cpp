@@ -254,12 +254,6 @@ int check_tick(smpc_ctx* c, const smpc_tick_in* in)
   if (((c->critics.obstacles.enabled && c->critics.obstacles.consider_footprint) ||
     (c->critics.cost.enabled && c->critics.cost.consider_footprint)) && c->fp_x.empty())
     return fail(c, SMPC_ERR_STATE, "consider_footprint=true needs a footprint: call smpc_set_footprint");
-  // with a footprint the two collision critics no longer see the same set of colliding
-  // rollouts, and the tuple carries one non-colliding count
-  if (c->critics.obstacles.enabled && c->critics.cost.enabled &&
-    (c->critics.obstacles.consider_footprint || c->critics.cost.consider_footprint))
-    return fail(c, SMPC_ERR_UNSUPPORTED,
-                "consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
   return SMPC_OK;
 }
 
@@ -969,6 +963,10 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
 
   predict_hint(c, in);
   c->gate_flags = gates;
+  // with a footprint the two collision critics no longer see the same set of colliding rollouts,
+  // and a pass reports one non-colliding count (CostCritic's, scored first): smpc_optimize counts
+  // ObstaclesCritic's with a pass of its own; the sharded tick and the grouped launch do not
+  c->two_coll_fp = (gates & SD_OBSTACLES) && (gates & SD_COST) && (gates & (SD_FP_OBSTACLES | SD_FP_COST));
   c->score_mode = mode_now;
   c->fail_in = in->fail_flag_in != 0;
   c->P = P;

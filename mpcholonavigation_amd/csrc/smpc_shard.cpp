@@ -59,6 +59,9 @@ int smpc_shard_begin(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   c->costs_cur = 0;
   const int rc = prepare_tick(c, in, u_in);
   if (rc != SMPC_OK) return rc;
+  if (c->two_coll_fp)
+    return fail(c, SMPC_ERR_UNSUPPORTED,
+                "sharded tick: consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
   // What smpc_shard_combine hands to the furthest-point predictor, copied: the caller owns *in
   // and its arrays and may free or reuse them as soon as this call returns (include/smpc.h:
   // "the library copies before returning and never retains host pointers").
@@ -284,6 +287,9 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
   c->costs_cur = 0;
   int rc = prepare_tick(c, in, u_inout);
   if (rc != SMPC_OK) return rc;
+  if (c->two_coll_fp)
+    return fail(c, SMPC_ERR_UNSUPPORTED,
+                "sharded tick: consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
   const uint32_t T = c->cfg.time_steps, TL = 4 + 3 * T, G = static_cast<uint32_t>(c->comm_world);
   auto nccl_ok = [&](ncclResult_t e, const char* what) {
     if (e == ncclSuccess) return SMPC_OK;

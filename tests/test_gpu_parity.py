@@ -575,6 +575,7 @@ def _extra_critics(names, power=1, **over):
     return cr
 
 
+FIVE_NAMES = ("obstacles", "path_align", "path_follow", "goal_angle", "prefer_forward")
 DEPLOYED = ("constraint", "cost", "goal", "goal_angle", "path_align", "path_follow", "path_angle",
             "prefer_forward", "twirling")      # robot_bringup/config/nav2_params.yaml:222
 ALL11 = DEPLOYED + ("obstacles", "velocity_deadband")
@@ -767,13 +768,97 @@ def test_consider_footprint_needs_a_footprint(Smpc):
     configure(g, scn, critics=cr, noise=noise)
     with pytest.raises(Exception, match="smpc_set_footprint"):
         g.optimize(scn.tick, scn.u0)
-    # both collision critics + a footprint: refused (they would disagree on who collides)
+
+
+@pytest.mark.parametrize("fp_obs,fp_cost,wall,expect", [
+    (1, 1, "beside", "some"),          # both check the footprint: some rollouts collide for each
+    (1, 0, "beside", "some"),
+    (0, 1, "beside", "some"),
+    (1, 0, "ahead", "obstacles"),      # every rollout's FOOTPRINT touches the wall, no centre does: Obstacles stops the manager
+    (0, 1, "ahead", "cost"),           # ... Cost does, before Obstacles is scored
+    (1, 1, "ahead", "cost")])
+@pytest.mark.parametrize("iters", [1, 2])
+def test_both_collision_critics_with_a_footprint(Smpc, Oracle, fp_obs, fp_cost, wall, expect, iters):
+    """CostCritic and ObstaclesCritic in one list with consider_footprint on either: they disagree on
+    which rollouts collide, each assigns fail_flag from its own collisions (cost_critic.cpp,
+    obstacles_critic.cpp:177) and the manager stops behind the first that finds every rollout
+    colliding (critic_manager.cpp:70-73).  A scoring pass reports ONE non-colliding count (Cost's,
+    scored first): smpc_optimize counts Obstacles' with a pass of its own and re-scores what the
+    reference had scored.  (Round 2 refused this configuration.)"""
+    from scipy import ndimage
+    B, T = (2000, 56) if wall == "beside" else (1024, 30)
+    cfg, scn, noise = make_case(B, T)
+    cfg.iteration_count = iters
+    res, t = scn.resolution, scn.tick
+    cx, cy = int(t.pose_x / res), int(t.pose_y / res)
+    cells = np.zeros_like(scn.cells)
+    u0 = scn.u0
+    if wall == "beside":
+        ix0, ix1 = int((t.pose_x + 0.3) / res), int((t.pose_x + 1.3) / res)
+        iy = int((t.pose_y + 0.35) / res)
+        cells[iy:iy + 2, ix0:ix1] = 254
+        d = ndimage.distance_transform_edt(cells != 254) * res
+        infl = np.where(d <= 0.1, 253, np.floor(252 * np.exp(-10.0 * (d - 0.1)))).astype(np.uint8)
+        infl[d > 0.55] = 0
+        cells = np.where(cells == 254, 254, infl).astype(np.uint8)
+    else:
+        cells[cy - 30:cy + 30, cx - 6:cx + 4] = 100
+        cells[cy - 30:cy + 30, cx + 4] = 254
+        scn.tick = Tick(t.pose_x, t.pose_y, 0.0, (0.0, 0.0, 0.0), t.path_x, t.path_y, t.path_yaw, t.goal_x, t.goal_y)
+        u0 = np.zeros_like(scn.u0)
+        u0[0] = -0.2
+    scn.cells = cells
+    cr = _extra_critics(("constraint", "cost", "obstacles", "path_follow", "prefer_forward", "goal"))
+    cr.obstacles.consider_footprint, cr.cost.consider_footprint = fp_obs, fp_cost
+    g, o = Smpc(cfg), Oracle(cfg)
+    for obj in (g, o):
+        configure(obj, scn, critics=cr, noise=noise)
+        obj.set_footprint(FOOTPRINT, circumscribed_radius=float(np.hypot(0.25, 0.18)), layer_cost_scaling_factor=10.0)
+    ug, og = g.optimize(scn.tick, u0)
+    uo, oo = o.optimize(scn.tick, u0)
+    assert og.fail_flag == oo.fail_flag == (0 if expect == "some" else 1)
+    assert og.non_colliding == oo.non_colliding
+    if expect == "some":
+        assert 0 < oo.non_colliding < B
+        assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=3, label=f"both critics fp {fp_obs}{fp_cost} x{iters}")
+    else:
+        cg, co = g.get_costs().astype(np.float64), o.get_costs().astype(np.float64)
+        assert np.max(np.abs(cg - co)) <= 4e-6 * float(np.max(np.abs(co))), (expect, cg[:4], co[:4])
+        assert rel_err(ug, uo) < 1e-3       # (every rollout at the collision cost: the weights hang on its last ulp)
+
+
+def test_sharded_tick_refuses_both_collision_critics_with_a_footprint(Smpc):
+    cfg, scn, noise = make_case(256, 30)
     cr = _extra_critics(("cost", "obstacles"))
     cr.cost.consider_footprint = 1
-    g.set_critics(cr)
+    g = Smpc(cfg)
+    configure(g, scn, critics=cr, noise=noise)
     g.set_footprint(FOOTPRINT, 0.31, 10.0)
-    with pytest.raises(Exception, match="both ObstaclesCritic and CostCritic"):
-        g.optimize(scn.tick, scn.u0)
+    with pytest.raises(Exception, match="sharded tick: consider_footprint=true with both"):
+        g.shard_begin(scn.tick, scn.u0)
+
+
+@pytest.mark.parametrize("B,T,names", [(2000, 56, FIVE_NAMES), (3000, 40, None)])
+def test_a_second_pass_of_an_iteration_reads_what_the_first_read(Smpc, B, T, names, monkeypatch):
+    """iteration_count > 1: iteration k starts from the control sequence iteration k - 1 left on the
+    device, and a re-score inside iteration k (all rollouts colliding, the counting pass above) must
+    start from the same one — the first pass's reduction has by then overwritten the result buffer.
+    SMPC_DEBUG_REPEAT_PASS launches every iteration's pass twice: same bits as once."""
+    cfg, scn, noise = make_case(B, T)
+    cfg.iteration_count = 3
+    cr = _extra_critics(names) if names else None
+    outs = []
+    for repeat in (False, True):
+        if repeat:
+            monkeypatch.setenv("SMPC_DEBUG_REPEAT_PASS", "1")
+        g = Smpc(cfg)
+        configure(g, scn, critics=cr, noise=noise)
+        u, out = g.optimize(scn.tick, scn.u0)
+        outs.append((u, out, g.get_costs()))
+    (u1, o1, c1), (u2, o2, c2) = outs
+    assert o2.passes == 2 * o1.passes
+    assert np.array_equal(u1, u2) and np.array_equal(c1, c2)
+    assert o1.min_cost == o2.min_cost and o1.sum_w == o2.sum_w
 
 
 @pytest.mark.parametrize("fp_critic,names", [("obstacles", ("obstacles", "path_follow", "prefer_forward")),

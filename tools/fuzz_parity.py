@@ -165,8 +165,6 @@ def build(d):
                     path_y=(oy + k * tick.path_y.astype(np.float64)).astype(np.float32), path_yaw=tick.path_yaw,
                     goal_x=float(np.float32(ox + k * tick.goal_x)), goal_y=float(np.float32(oy + k * tick.goal_y)),
                     goal_checker_xy_tolerance=tick.goal_checker_xy_tolerance)
-    if d["footprint"] and "obstacles" in d["critics"] and "cost" in d["critics"]:
-        d["footprint"] = ""      # refused by the library (SMPC_ERR_UNSUPPORTED): both collision critics with a footprint
     if d["footprint"]:
         if d["footprint"] in ("obstacles", "both") and "obstacles" in d["critics"]:
             cr.obstacles.consider_footprint = 1
