@@ -456,7 +456,10 @@ int smpc_set_profile(smpc_ctx* ctx, int enable);
 /* Length in floats of one shard tuple: SMPC_TUPLE_HEADER + 3*T. */
 uint32_t smpc_tuple_len(const smpc_ctx* ctx);
 
-/* Upload the tick's inputs and control sequence (host pointers).  Everything the later phases
+/* (The sharded tick — these phases and smpc_shard_tick — runs ONE iteration per tick: a ctx with
+ * iteration_count != 1 is refused with SMPC_ERR_UNSUPPORTED, as is consider_footprint with both
+ * collision critics in the list.)
+ * Upload the tick's inputs and control sequence (host pointers).  Everything the later phases
  * of the tick need (smpc_shard_combine feeds the path and the pose to the furthest-point
  * predictor) is copied before this returns: *in, its arrays and u_in are the caller's again. */
 int smpc_shard_begin(smpc_ctx* ctx, const smpc_tick_in* in, const float* u_in);

@@ -62,6 +62,8 @@ int smpc_shard_begin(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   if (c->two_coll_fp)
     return fail(c, SMPC_ERR_UNSUPPORTED,
                 "sharded tick: consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
+  if (c->cfg.iteration_count != 1)   // (one exchange = one iteration; never silently fewer than asked for)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "sharded tick: iteration_count must be 1");
   // What smpc_shard_combine hands to the furthest-point predictor, copied: the caller owns *in
   // and its arrays and may free or reuse them as soon as this call returns (include/smpc.h:
   // "the library copies before returning and never retains host pointers").
@@ -290,6 +292,8 @@ int smpc_shard_tick(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_ti
   if (c->two_coll_fp)
     return fail(c, SMPC_ERR_UNSUPPORTED,
                 "sharded tick: consider_footprint=true with both ObstaclesCritic and CostCritic in the list");
+  if (c->cfg.iteration_count != 1)   // (one exchange = one iteration; never silently fewer than asked for)
+    return fail(c, SMPC_ERR_UNSUPPORTED, "sharded tick: iteration_count must be 1");
   const uint32_t T = c->cfg.time_steps, TL = 4 + 3 * T, G = static_cast<uint32_t>(c->comm_world);
   auto nccl_ok = [&](ncclResult_t e, const char* what) {
     if (e == ncclSuccess) return SMPC_OK;

@@ -836,6 +836,16 @@ def test_sharded_tick_refuses_both_collision_critics_with_a_footprint(Smpc):
     g.set_footprint(FOOTPRINT, 0.31, 10.0)
     with pytest.raises(Exception, match="sharded tick: consider_footprint=true with both"):
         g.shard_begin(scn.tick, scn.u0)
+    # ... and more than one iteration per tick (it would silently run one)
+    cfg2, scn2, noise2 = make_case(256, 30)
+    cfg2.iteration_count = 2
+    g2 = Smpc(cfg2)
+    configure(g2, scn2, noise=noise2)
+    with pytest.raises(Exception, match="sharded tick: iteration_count must be 1"):
+        g2.shard_begin(scn2.tick, scn2.u0)
+    g2.shard_comm_init(g2.shard_comm_id(), 0, 1)          # (a one-rank communicator: the tick gets as far as its checks)
+    with pytest.raises(Exception, match="sharded tick: iteration_count must be 1"):
+        g2.shard_tick(scn2.tick, scn2.u0)
 
 
 @pytest.mark.parametrize("B,T,names", [(2000, 56, FIVE_NAMES), (3000, 40, None)])
