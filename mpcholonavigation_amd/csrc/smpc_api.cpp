@@ -958,6 +958,7 @@ int smpc_optimize(smpc_ctx* c, const smpc_tick_in* in, float* u_inout, smpc_tick
   for (uint32_t it = 0; it < c->cfg.iteration_count; ++it) {
     uint32_t flags = scoring_flags(c, fail_sticky);
     if (it > 0) flags |= SD_ACCUMULATE;
+    have_nc_obstacles = false;   // (the count reported is the LAST iteration's, like every other output)
     // a later iteration starts from what the previous one left in d_out — from a COPY of it: the
     // reduction of this iteration's first pass overwrites d_out, and a second pass of the same
     // iteration (speculation miss, all-collide re-score, the counting pass below) has to read
