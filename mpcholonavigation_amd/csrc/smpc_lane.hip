@@ -389,7 +389,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     // entry 256; drained after the loop.
     uint32_t cell_q = 256u;
     f32x2 e_q = {0.f, 0.f};   // {crit, rep} of SmpcLut
-    const uint32_t lds_lut = (uint32_t)(uintptr_t)s_lut, lds_map = (uint32_t)(uintptr_t)s_map;
+    [[maybe_unused]] const uint32_t lds_lut = (uint32_t)(uintptr_t)s_lut, lds_map = (uint32_t)(uintptr_t)s_map;   // (LANE_X_PIN_LDS)
     auto lookup_wait = [&]() {   // both reads of the previous step have landed
 #if LANE_X_PIN_LDS
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cell_q), "+v"(e_q));
@@ -635,7 +635,7 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
     // four steps; each parks its noised controls at once (LANE_X_PARK_STEP) or the quad returns
     // them in cq[3 i + ctrl] for the caller to park
     auto run_quad = [&](auto hi_c, const uint32_t q, float (&cq)[12]) {
-      constexpr bool HI = decltype(hi_c)::value;
+      [[maybe_unused]] constexpr bool HI = decltype(hi_c)::value;
       // The two waves of a SIMD do not share it evenly by themselves: the older one wins every
       // tie and finishes its groups ~25 % sooner (41 us against 51 us for two groups), then the
       // younger one runs alone.  Swapping their priorities every 2^15 shader clocks — by the clock,
