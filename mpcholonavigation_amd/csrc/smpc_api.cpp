@@ -590,7 +590,13 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
     int large_bar = 0;
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) large_bar = 0;
     c->bar_tick = large_bar != 0 && getenv("SMPC_NO_BAR_TICK") == nullptr;
-    if (c->bar_tick && !getenv("SMPC_NO_HDP_FLUSH")) c->hdp_flush = find_hdp_flush(dev);
+    if (c->bar_tick && !getenv("SMPC_NO_HDP_FLUSH")) {
+      c->hdp_flush = find_hdp_flush(dev);
+      // without the device's HDP flush register the stores may sit in the host data path's
+      // cache when the pass starts: such a device takes the stream copy (SMPC_NO_HDP_FLUSH=1, an
+      // experiment, keeps the stores without the flush; the canary then guards every tick)
+      if (!c->hdp_flush) c->bar_tick = false;
+    }
   }
   CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
