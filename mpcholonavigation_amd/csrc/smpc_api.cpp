@@ -645,6 +645,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
     }
     c->knob_no_split = getenv("SMPC_NO_SPLIT") != nullptr;
     c->knob_repeat_pass = getenv("SMPC_DEBUG_REPEAT_PASS") != nullptr;
+    if (const char* e = getenv("SMPC_DEBUG_STALE_TICK")) c->knob_stale_tick = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("SMPC_SPLIT_NSEG")) c->knob_split_nseg = static_cast<uint32_t>(std::max(0, atoi(e)));
     if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) tpr = false;   // visualisation path: wave pass
     if (3ull * n >= (1ull << 32)) tpr = false;   // its buffer descriptor spans the three noise tensors
@@ -1257,6 +1258,10 @@ int smpc_debug_lane_timeline(smpc_ctx* c, double* out, uint32_t* n_blocks)
 // developer aid (bench.py labels its roofline with it): the scoring-pass instance the calling
 // thread launched last, spelled as rocprofv3's kernel trace spells it
 const char* smpc_debug_last_pass_kernel(void) {return smpc_last_pass_kernel;}
+
+// developer aid: how this ctx hands its per-tick inputs to the device — 1: CPU stores through the
+// PCIe BAR, 0: a copy on the stream (or, for wave-pass contexts, inside the kernel arguments)
+int smpc_debug_bar_tick(const smpc_ctx* c) {return c && c->bar_tick ? 1 : 0;}
 
 int smpc_set_profile(smpc_ctx* c, int enable)
 {

@@ -187,6 +187,7 @@ struct smpc_ctx {
   bool lane_forced = false;              // SMPC_FLAG_LANE_PER_ROLLOUT / SMPC_PASS=lane|split: the lane pass below kLaneMinBatch too
   bool knob_no_split = false;            // SMPC_NO_SPLIT=1
   bool knob_repeat_pass = false;         // SMPC_DEBUG_REPEAT_PASS=1 (tests): every iteration's scoring pass is launched twice
+  uint32_t knob_stale_tick = 0;          // SMPC_DEBUG_STALE_TICK=n (tests): the BAR hand-over skips tick n's block
   bool two_coll_fp = false;              // this tick: BOTH collision critics scored and a consider_footprint switch set —
                                          // they then disagree on which rollouts collide (smpc_optimize: a counting pass)
   bool knob_force_split = false;         // SMPC_PASS=split: wherever the instance applies, whatever the batch

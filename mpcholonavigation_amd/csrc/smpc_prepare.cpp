@@ -821,8 +821,13 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
       HIPCK(c, hipStreamSynchronize(c->stream));
       c->launched = false;
     }
-    bar_copy(c->d_tick, h, tl.total);
-    bar_flush(c);
+    // SMPC_DEBUG_STALE_TICK=n (tests of the guard): tick n's block is NOT handed over — the pass
+    // reads the previous tick's, echoes its number, and fetch_out has to fail the tick
+    if (c->knob_stale_tick && c->tick_no == c->knob_stale_tick) {
+    } else {
+      bar_copy(c->d_tick, h, tl.total);
+      bar_flush(c);
+    }
   } else if (!c->defer_upload && !pinned_tick) {
     if (!inline_tick)
       HIPCK(c, hipMemcpyAsync(c->d_tick, h, tl.total, hipMemcpyHostToDevice, c->stream));

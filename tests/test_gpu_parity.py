@@ -475,6 +475,47 @@ def test_pass_chosen_by_size(Smpc, Oracle, B, T, kind):
     assert_parity(ug, og, uo, oo, g.get_costs(), o.get_costs(), max_flips=2, label=f"chosen {B}x{T}")
 
 
+def test_a_stale_tick_block_fails_the_tick_and_the_context_recovers(Smpc, monkeypatch):
+    """The per-tick inputs reach the device by CPU stores through the PCIe BAR, guarded
+    by the tick's number: the pass echoes the number of the block it read, and a tick whose pass read
+    another tick's block fails loudly.  SMPC_DEBUG_STALE_TICK=3 withholds the third tick's block: that
+    tick must fail (not return the second tick's answer), the context falls back to the stream copy,
+    and the next tick is what a context that never saw the fault computes."""
+    import ctypes
+    cfg, scn, noise = make_case(4096, 64)
+    cfg.flags |= A.SMPC_FLAG_LANE_PER_ROLLOUT
+
+    def bar(g):
+        f = g.lib.smpc_debug_bar_tick
+        f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p]
+        return f(g.h)
+
+    good = Smpc(cfg)
+    if not bar(good):
+        pytest.skip("this device hands the tick block over by a stream copy (no large BAR / no HDP flush register)")
+    monkeypatch.setenv("SMPC_DEBUG_STALE_TICK", "3")
+    bad = Smpc(cfg)
+    monkeypatch.delenv("SMPC_DEBUG_STALE_TICK")
+    for g in (good, bad):
+        configure(g, scn, noise=noise)
+    t = scn.tick
+    ticks = [Tick(t.pose_x + 0.03 * k, t.pose_y, t.pose_yaw + 0.02 * k, t.speed, t.path_x, t.path_y, t.path_yaw, t.goal_x, t.goal_y)
+             for k in range(5)]
+    for k in range(2):
+        ug, _ = good.optimize(ticks[k], scn.u0)
+        ub, _ = bad.optimize(ticks[k], scn.u0)
+        assert np.array_equal(ug, ub)
+    good.optimize(ticks[2], scn.u0)
+    with pytest.raises(Exception, match="read tick block 2, not 3"):
+        bad.optimize(ticks[2], scn.u0)
+    assert bar(good) == 1 and bar(bad) == 0          # the faulted context takes the copy from now on
+    for k in (3, 4):
+        ug, og = good.optimize(ticks[k], scn.u0)
+        ub, ob = bad.optimize(ticks[k], scn.u0)
+        assert np.array_equal(ug, ub) and np.array_equal(good.get_costs(), bad.get_costs()), k
+        assert og.furthest_reached_path_point == ob.furthest_reached_path_point
+
+
 def test_windowed_furthest_scan_falls_back_exactly(Smpc, Oracle):
     """The lane pass scans the endpoint's nearest path point from three blocks below the scored
     index up and verifies the rest for the wave's winner (smpc_lane.hip).  Paths on which that
