@@ -351,33 +351,32 @@ uint32_t scoring_flags(const smpc_ctx* c, bool fail_sticky)
   return fail_sticky ? (c->gate_flags & keep) : c->gate_flags;
 }
 
-// keep the time-major copies in step with the [B,T] tensors
+// keep the group-major copies (smpc_dev.h: SMPC_GM_INDEX) in step with the [B,T] tensors
 int update_time_major(smpc_ctx* c)
 {
   if (!c->use_tpr) return SMPC_OK;
   const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
-  HIPCK(c, smpc_launch_transpose(c->d_nvx, c->d_tvx, B, T, c->stream));
-  HIPCK(c, smpc_launch_transpose(c->d_nvy, c->d_tvy, B, T, c->stream));
-  HIPCK(c, smpc_launch_transpose(c->d_nwz, c->d_twz, B, T, c->stream));
+  HIPCK(c, smpc_launch_relayout(c->d_nvx, c->d_tvx, B, T, true, c->stream));
+  HIPCK(c, smpc_launch_relayout(c->d_nvy, c->d_tvy, B, T, true, c->stream));
+  HIPCK(c, smpc_launch_relayout(c->d_nwz, c->d_twz, B, T, true, c->stream));
   return SMPC_OK;
 }
 
-// the [B,T] tensors (wave-per-rollout pass, smpc_get_noise) from the time-major copy, when a
+// the [B,T] tensors (wave-per-rollout pass, smpc_get_noise) from the group-major copy, when a
 // device-RNG draw filled only that one
 int ensure_row_major(smpc_ctx* c)
 {
   if (c->rm_valid) return SMPC_OK;
   const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
-  // [T][B] -> [B][T] is the same tiled transpose with the roles of the dimensions swapped
-  HIPCK(c, smpc_launch_transpose(c->d_tvx, c->d_nvx, T, B, c->stream));
-  if (c->holonomic) HIPCK(c, smpc_launch_transpose(c->d_tvy, c->d_nvy, T, B, c->stream));
-  HIPCK(c, smpc_launch_transpose(c->d_twz, c->d_nwz, T, B, c->stream));
+  HIPCK(c, smpc_launch_relayout(c->d_tvx, c->d_nvx, B, T, false, c->stream));
+  if (c->holonomic) HIPCK(c, smpc_launch_relayout(c->d_tvy, c->d_nvy, B, T, false, c->stream));
+  HIPCK(c, smpc_launch_relayout(c->d_twz, c->d_nwz, B, T, false, c->stream));
   c->rm_valid = true;
   return SMPC_OK;
 }
 
 // One epoch of the device RNG into the given set of tensors, on stream st (no wait).
-// rm_valid_out: whether the [B,T] tensors of the set hold the draw (else only the time-major ones)
+// rm_valid_out: whether the [B,T] tensors of the set hold the draw (else only the group-major ones)
 static int launch_draw(smpc_ctx* c, float* nvx, float* nvy, float* nwz, float* tvx, float* tvy, float* twz,
                        hipStream_t st, bool* rm_valid_out)
 {
@@ -385,7 +384,7 @@ static int launch_draw(smpc_ctx* c, float* nvx, float* nvy, float* nwz, float* t
   const uint64_t base = c->cfg.shard_offset * c->cfg.time_steps;
   const uint32_t B = c->cfg.batch_size, T = c->cfg.time_steps;
   if (c->use_tpr && (T & 3u) == 0 && !getenv("SMPC_NO_FUSED_FILL")) {
-    // lane-per-rollout contexts: draw straight into the time-major layout that pass reads —
+    // lane-per-rollout contexts: draw straight into the group-major layout that pass reads —
     // one write of the noise instead of a write, a read and a second write (fill + transpose);
     // the [B,T] copy is made only if something asks for it (ensure_row_major)
     HIPCK(c, smpc_launch_fill_noise_tm(tvx, B, T, base, c->seed, 0, c->epoch, c->cfg.vx_std, st));
@@ -393,7 +392,7 @@ static int launch_draw(smpc_ctx* c, float* nvx, float* nvy, float* nwz, float* t
     if (c->holonomic)
       HIPCK(c, smpc_launch_fill_noise_tm(tvy, B, T, base, c->seed, 2, c->epoch, c->cfg.vy_std, st));
     else
-      HIPCK(c, hipMemsetAsync(tvy, 0, n * sizeof(float), st));
+      HIPCK(c, hipMemsetAsync(tvy, 0, static_cast<size_t>(SMPC_GM_ROLLOUTS(B)) * T * sizeof(float), st));
     *rm_valid_out = false;
     return SMPC_OK;
   }
@@ -403,9 +402,9 @@ static int launch_draw(smpc_ctx* c, float* nvx, float* nvy, float* nwz, float* t
   // noises_vy_ keeps its zeros for a non-holonomic model (noise_generator.cpp:117-121)
   if (c->holonomic) HIPCK(c, smpc_launch_fill_noise(nvy, n, base, c->seed, 2, c->epoch, c->cfg.vy_std, st));
   if (c->use_tpr) {
-    HIPCK(c, smpc_launch_transpose(nvx, tvx, B, T, st));
-    HIPCK(c, smpc_launch_transpose(nvy, tvy, B, T, st));
-    HIPCK(c, smpc_launch_transpose(nwz, twz, B, T, st));
+    HIPCK(c, smpc_launch_relayout(nvx, tvx, B, T, true, st));
+    HIPCK(c, smpc_launch_relayout(nvy, tvy, B, T, true, st));
+    HIPCK(c, smpc_launch_relayout(nwz, twz, B, T, true, st));
   }
   *rm_valid_out = true;
   return SMPC_OK;
@@ -465,9 +464,10 @@ int redraw_async(smpc_ctx* c)
     HIPCK(c, hipEventCreateWithFlags(&c->ev_fill, hipEventDisableTiming));
   }
   if (c->use_tpr && !c->b_tvx) {
-    HIPCK(c, hipMalloc(&c->b_tvx, 3 * n));
-    c->b_tvy = c->b_tvx + n / sizeof(float);
-    c->b_twz = c->b_tvy + n / sizeof(float);
+    const size_t ngm = static_cast<size_t>(SMPC_GM_ROLLOUTS(c->cfg.batch_size)) * c->cfg.time_steps * sizeof(float);
+    HIPCK(c, hipMalloc(&c->b_tvx, 3 * ngm));
+    c->b_tvy = c->b_tvx + ngm / sizeof(float);
+    c->b_twz = c->b_tvy + ngm / sizeof(float);
   }
   if (!c->b_nvx) {
     HIPCK(c, hipMalloc(&c->b_nvx, n));
@@ -621,7 +621,7 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
     // which streaming pass: a wave per rollout (latency, small batches) or a lane per
     // rollout (throughput, large batches); SMPC_PASS=wave|lane overrides for experiments
     bool tpr = cfg->batch_size >= kLaneMinBatch && cfg->time_steps <= kLaneMaxT;
-    // (smpc_pass_split, T = 64: the time-major noise from kSplitMinBatch rollouts up; plan_launch keeps
+    // (smpc_pass_split, T = 64: the group-major noise from kSplitMinBatch rollouts up; plan_launch keeps
     // the lane pass itself for batches from kLaneMinBatch up, unless it is asked for)
     if (cfg->time_steps <= 64 && cfg->time_steps >= 36 && (cfg->time_steps & 3u) == 0 && cfg->batch_size >= kSplitMinBatch &&
         !getenv("SMPC_NO_SPLIT"))
@@ -648,13 +648,16 @@ int smpc_create(const smpc_config* cfg, smpc_ctx** out)
     if (const char* e = getenv("SMPC_DEBUG_STALE_TICK")) c->knob_stale_tick = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("SMPC_SPLIT_NSEG")) c->knob_split_nseg = static_cast<uint32_t>(std::max(0, atoi(e)));
     if (cfg->flags & SMPC_FLAG_STORE_TRAJECTORIES) tpr = false;   // visualisation path: wave pass
-    if (3ull * n >= (1ull << 32)) tpr = false;   // its buffer descriptor spans the three noise tensors
+    // the group-major copies (smpc_dev.h: SMPC_GM_INDEX): the batch padded to whole groups of 64
+    const size_t ngm = static_cast<size_t>(SMPC_GM_ROLLOUTS(cfg->batch_size)) * T * sizeof(float);
+    if (3ull * ngm >= (1ull << 32)) tpr = false;   // its buffer descriptor spans the three noise tensors
     c->use_tpr = tpr;
     if (tpr) {
       // back to back: the lane pass addresses the three through one buffer descriptor
-      CK(hipMalloc(&c->d_tvx, 3 * n));
-      c->d_tvy = c->d_tvx + n / sizeof(float);
-      c->d_twz = c->d_tvy + n / sizeof(float);
+      CK(hipMalloc(&c->d_tvx, 3 * ngm));
+      c->d_tvy = c->d_tvx + ngm / sizeof(float);
+      c->d_twz = c->d_tvy + ngm / sizeof(float);
+      if (!c->holonomic) CK(hipMemset(c->d_tvy, 0, ngm));
       CK(smpc_lane_set_lds_limit(static_cast<int>(kLdsPerCu)));
       CK(smpc_split_set_lds_limit(static_cast<int>(kLdsPerCu)));
     }

@@ -53,7 +53,7 @@ hipError_t smpc_launch_p2p_exchange(const float* my_tuple, const SmpcP2P& x, uin
                                     const float* furthest_used, float* host_out, uint32_t seq,
                                     hipStream_t st);
 
-hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T, hipStream_t st);
+hipError_t smpc_launch_relayout(const float* src, float* dst, uint32_t B, uint32_t T, bool to_gm, hipStream_t st);
 hipError_t smpc_launch_pass_lane(const SmpcDev& p, const SmpcLds& L, uint32_t grid, bool rr, uint32_t block, hipStream_t st);
 uint32_t smpc_lane_block();
 uint32_t smpc_lane_block_rr();
@@ -156,7 +156,7 @@ struct smpc_ctx {
   float* d_nvx = nullptr;
   float* d_nvy = nullptr;
   float* d_nwz = nullptr;
-  float* d_tvx = nullptr;       // time-major [T,B] copies for the lane-per-rollout pass:
+  float* d_tvx = nullptr;       // group-major copies (smpc_dev.h: SMPC_GM_INDEX) for the lane-per-rollout and split passes:
   float* d_tvy = nullptr;       // one allocation, vy and wz follow vx
   float* d_twz = nullptr;
   // A second set of noise tensors for smpc_redraw_noise_async (regenerate_noises = true): the
@@ -173,9 +173,9 @@ struct smpc_ctx {
   bool redraw_pending = false, redraw_rm_valid = true;
   uint32_t noise_gen = 0;              // counts changes of the noise the ticks score with
   uint32_t noise_gen_remembered = 0;   // ... as of the last remember_furthest
-  bool use_tpr = false;      // time-major noise kept: the lane-per-rollout pass may run
+  bool use_tpr = false;      // group-major noise kept: the lane-per-rollout pass may run
   bool rm_valid = true;      // the [B,T] tensors hold the current noise (a device-RNG draw fills the
-                             // time-major copy only; ensure_row_major() makes the other on demand)
+                             // group-major copy only; ensure_row_major() makes the other on demand)
   bool lane_now = false;     // ... and does for this tick (lean scoring mode)
   bool split_now = false;    // ... as smpc_pass_split (lane = rollout x quarter of the horizon): small batches at T = 64
   SmpcLds lds_split{};

@@ -30,6 +30,14 @@
 #define SD_EXTRA_CRITICS (SD_CONSTRAINT | SD_COST | SD_GOAL | SD_TWIRLING | SD_PATH_ANGLE | SD_DEADBAND | \
                           SD_FP_OBSTACLES | SD_FP_COST | SD_PATH_ALIGN_LEGACY)
 
+// Layout of the noise the lane-per-rollout and split passes read ("group-major"): element (b, t) of
+// a [B, T] tensor sits at ((b / 64) T + t) 64 + b % 64 — the 64 rollouts of a wave-group and their T
+// steps are one run of 256 T bytes, where the time-major [T][B] layout of rounds 1-2 put a group's
+// consecutive steps B x 4 bytes (8 MB at the bench size) apart: one page per step and tensor
+// (measured at 2 097 152 x 64: 391 -> 376 us per pass).  B is padded to a multiple of 64.
+#define SMPC_GM_ROLLOUTS(B) ((((B) + 63u) / 64u) * 64u)
+#define SMPC_GM_INDEX(b, t, T) ((((size_t)(b) >> 6) * (T) + (t)) * 64u + ((b) & 63u))
+
 #define SMPC_MAX_PATH 1024        // path points staged in LDS
 #define SMPC_MAX_R 4              // time steps per lane (T <= 64 * SMPC_MAX_R)
 
@@ -64,7 +72,7 @@ struct SmpcDev {
   const float* nvx;         // noise [B,T] (reference layout; wave-per-rollout pass)
   const float* nvy;
   const float* nwz;
-  const float* tvx;         // the same noise time-major [T,B] (lane-per-rollout pass)
+  const float* tvx;         // the same noise group-major (SMPC_GM_INDEX; lane-per-rollout and split passes)
   const float* tvy;
   const float* twz;
   const float* u;           // [3T] control sequence (device)

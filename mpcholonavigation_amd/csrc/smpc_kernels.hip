@@ -1551,9 +1551,9 @@ __global__ void __launch_bounds__(256) smpc_fill_noise(float* __restrict__ out, 
   }
 }
 
-// The same stream written TIME-MAJOR, dst[t * B + b] (the layout the lane-per-rollout pass
-// reads): thread (b, group of four steps) with b fastest, so a wave writes four coalesced
-// 256-byte row pieces.  Element e = base + b * T + t of the global [B_global, T] tensor is word
+// The same stream written GROUP-MAJOR (SMPC_GM_INDEX, smpc_dev.h: the layout the lane-per-rollout
+// and split passes read): thread (b, group of four steps) with b fastest, so a wave writes four
+// coalesced 256-byte pieces.  Element e = base + b * T + t of the global [B_global, T] tensor is word
 // e % 4 of Philox block e / 4 exactly as in smpc_fill_noise; T must be a multiple of four, so
 // that a block never straddles two rollouts (base is a multiple of T).
 __global__ void __launch_bounds__(256) smpc_fill_noise_tm(float* __restrict__ dst, uint32_t B, uint32_t T,
@@ -1570,7 +1570,7 @@ __global__ void __launch_bounds__(256) smpc_fill_noise_tm(float* __restrict__ ds
     box_muller(r[0], r[1], z[0], z[1]);
     box_muller(r[2], r[3], z[2], z[3]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dst[(size_t)(4u * tq + (uint32_t)k) * B + b] = z[k] * sigma;
+    for (int k = 0; k < 4; ++k) dst[SMPC_GM_INDEX(b, 4u * tq + (uint32_t)k, T)] = z[k] * sigma;
   }
 }
 

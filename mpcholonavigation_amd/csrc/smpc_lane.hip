@@ -10,8 +10,8 @@
 //     the float cumulative sums run in the reference's own sequential order
 //     (optimizer.cpp:313-343);
 //   * everything uniform over the batch (u[t], map geometry, weights) sits in SGPRs;
-//   * noise is read from a time-major copy [T][B]: one coalesced 256-B row piece per array
-//     and step, prefetched four steps ahead;
+//   * noise is read from a group-major copy [B / 64][T][64] (smpc_dev.h): one coalesced 256-B
+//     piece per array and step, a group's steps back to back, prefetched four steps ahead;
 //   * the noised controls of the 64 rollouts stay PARKED IN REGISTERS (3 x 64 per lane)
 //     until the rollouts' costs, hence softmax weights, are known; then
 //     U[t] += sum_b w_b c[b][t] is a 64 x 64 transpose-reduce done in registers:
@@ -79,38 +79,45 @@
 #endif
 
 // ---------------------------------------------------------------------------
-// [B][T] -> [T][B] (one-off, after the noise is drawn or supplied)
+// [B][T] row-major <-> group-major (SMPC_GM_INDEX, smpc_dev.h): one-off, after the noise is supplied
+// (or drawn row-major), and back when something asks for the [B, T] tensors of a group-major draw
 // ---------------------------------------------------------------------------
-// SWAP: the tile index of the second dimension rides on blockIdx.x (the grid's x extent is the
-// one without a 65 535 limit: the larger dimension goes there)
-template <bool SWAP>
-__global__ void __launch_bounds__(256) smpc_transpose_bt(const float* __restrict__ src,
-                                                        float* __restrict__ dst, uint32_t B,
-                                                        uint32_t T)
+template <bool TO_GM>
+__global__ void __launch_bounds__(256) smpc_relayout(const float* __restrict__ src, float* __restrict__ dst,
+                                                    uint32_t B, uint32_t T)
 {
   __shared__ float tile[32][33];
-  const uint32_t bx = (SWAP ? blockIdx.y : blockIdx.x) * 32, ty0 = (SWAP ? blockIdx.x : blockIdx.y) * 32;
+  const uint32_t b0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
   const uint32_t lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
-  for (uint32_t k = ly; k < 32; k += 8) {
-    const uint32_t b = bx + k, t = ty0 + lx;
-    tile[k][lx] = (b < B && t < T) ? src[(size_t)b * T + t] : 0.f;
-  }
-  __syncthreads();
-  for (uint32_t k = ly; k < 32; k += 8) {
-    const uint32_t t = ty0 + k, b = bx + lx;
-    if (b < B && t < T) dst[(size_t)t * B + b] = tile[lx][k];
+  if (TO_GM) {
+    for (uint32_t k = ly; k < 32; k += 8) {      // rows of the [B][T] tensor: coalesced along t
+      const uint32_t b = b0 + k, t = t0 + lx;
+      tile[k][lx] = (b < B && t < T) ? src[(size_t)b * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (uint32_t k = ly; k < 32; k += 8) {      // 32 rollouts of one group at one step: 128 bytes in a row
+      const uint32_t t = t0 + k, b = b0 + lx;
+      if (b < B && t < T) dst[SMPC_GM_INDEX(b, t, T)] = tile[lx][k];
+    }
+  } else {
+    for (uint32_t k = ly; k < 32; k += 8) {
+      const uint32_t t = t0 + k, b = b0 + lx;
+      tile[lx][k] = (b < B && t < T) ? src[SMPC_GM_INDEX(b, t, T)] : 0.f;
+    }
+    __syncthreads();
+    for (uint32_t k = ly; k < 32; k += 8) {
+      const uint32_t b = b0 + k, t = t0 + lx;
+      if (b < B && t < T) dst[(size_t)b * T + t] = tile[k][lx];
+    }
   }
 }
 
-// src [B][T] -> dst [T][B]
-hipError_t smpc_launch_transpose(const float* src, float* dst, uint32_t B, uint32_t T,
-                                 hipStream_t st)
+// to_gm: src [B][T] -> dst group-major; else src group-major -> dst [B][T]
+hipError_t smpc_launch_relayout(const float* src, float* dst, uint32_t B, uint32_t T, bool to_gm, hipStream_t st)
 {
-  const uint32_t nb = (B + 31) / 32, nt = (T + 31) / 32;
-  if (nt > nb)
-    hipLaunchKernelGGL(smpc_transpose_bt<true>, dim3(nt, nb), dim3(256), 0, st, src, dst, B, T);
-  else
-    hipLaunchKernelGGL(smpc_transpose_bt<false>, dim3(nb, nt), dim3(256), 0, st, src, dst, B, T);
+  const dim3 grid((B + 31) / 32, (T + 31) / 32);
+  if (to_gm) hipLaunchKernelGGL(smpc_relayout<true>, grid, dim3(256), 0, st, src, dst, B, T);
+  else hipLaunchKernelGGL(smpc_relayout<false>, grid, dim3(256), 0, st, src, dst, B, T);
   return hipGetLastError();
 }
 
@@ -295,14 +302,13 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
   // so that uniform loads stay scalar loads although the kernel also stores to global memory
   const cfloat_p cu = (cfloat_p)(uintptr_t)p.u;
   const uint32_t T = FULL ? 64u * NCH : (TC ? (uint32_t)TC : p.T), B = p.B;
-  // time-major noise through buffer loads: per step one scalar offset (t * B * 4) serves the
-  // three tensors, the lane's own offset (b * 4) is the vector offset
-  // (the host lays the three [T,B] tensors out back to back: ONE descriptor, four scalar
+  // group-major noise through buffer loads: per step one scalar offset (t * 256) serves the
+  // three tensors, the lane's own offset (its group's start + lane * 4) is the vector offset
+  // (the host lays the three tensors out back to back: ONE descriptor, four scalar
   // registers instead of twelve — the loop is short of them — and the tensor is part of the
   // scalar offset)
-  const uint32_t noise_bytes = T * B * 4u;
+  const uint32_t noise_bytes = T * SMPC_GM_ROLLOUTS(B) * 4u;   // one tensor, group-major (smpc_dev.h)
   const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvx), 0, 3u * noise_bytes, 0x00020000);
-  const uint32_t row_bytes = B * 4u;
   const float dt = p.dt, yaw0 = p.yaw0;
   const double x0 = p.x0, y0 = p.y0;
   uint32_t S = 0;
@@ -612,14 +618,16 @@ smpc_pass_lane(const SmpcDev p0, const SmpcLds L, const SmpcDev* __restrict__ ma
       }
     };
 
-    // noise, time-major: row t is a uniform base + this lane's offset; four steps in flight.
+    // noise: step t is a uniform base + this lane's offset; four steps in flight.
     // The control sequence of the next four steps is fetched (scalar loads) a quad ahead too.
-    const uint32_t loff = bl * 4u;
+    // noise, group-major: step t of this wave's 64 rollouts is 256 bytes behind step t - 1
+    const uint32_t loff = ((bl >> 6) * T * 64u + (bl & 63u)) * 4u;   // SMPC_GM_INDEX(bl, 0, T) in 32 bits: the descriptor spans < 4 GB
+    constexpr uint32_t step_bytes = 256u;
     auto ld = [&](uint32_t tensor, uint32_t t) -> float {
       // (the whole-quads instances of T < 64 prefetch unconditionally — see run_quad — so their
       // last quad's prefetch is clamped to the last row; T = 64: never out of range)
       const uint32_t tc = (FULL || t < T) ? t : T - 1;
-      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, loff, tensor * noise_bytes + tc * row_bytes, 0));
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, loff, tensor * noise_bytes + tc * step_bytes, 0));
     };
     auto ldu = [&](uint32_t ctrl, uint32_t t) -> float {return cu[ctrl * T + ((FULL || t < T) ? t : T - 1)];};
     float nq[12], uq[12];

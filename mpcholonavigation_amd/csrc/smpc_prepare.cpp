@@ -600,7 +600,7 @@ static int plan_launch(smpc_ctx* c, const smpc_tick_in* in, uint32_t gates, uint
   }
 
   // below kLaneMinBatch the lane pass itself loses to the wave pass (one group per CU's worth of
-  // waves: crossover measured at ~50 k rollouts); such contexts keep the time-major noise only
+  // waves: crossover measured at ~50 k rollouts); such contexts keep the group-major noise only
   // for the split form
   if (c->lane_now && !c->split_now && B < kLaneMinBatch && !c->lane_forced) c->lane_now = false;
 

@@ -259,9 +259,9 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
 
   // ---- constants ------------------------------------------------------------------------------
   const uint32_t B = p.B;
-  const uint32_t noise_bytes = T * B * 4u;
+  const uint32_t noise_bytes = T * SMPC_GM_ROLLOUTS(B) * 4u;   // one tensor, group-major (smpc_dev.h)
   const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tvx), 0, 3u * noise_bytes, 0x00020000);
-  const uint32_t row_bytes = B * 4u;
+  constexpr uint32_t row_bytes = 256u;                         // step t + 1 of a 64-rollout group: 256 bytes on
   const float dt = p.dt, yaw0 = p.yaw0;
   const double x0 = p.x0, y0 = p.y0;
   uint32_t S = 0;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 2) smpc_pass_split(const SmpcDev 
     const uint32_t bl = live ? b : B - 1;
     // noise row t0 + i of this lane: the lane's own part (rollout, first row of its segment) is the
     // vector offset, tensor and i the scalar one; the row in front of the segment separately
-    const uint32_t voff = bl * 4u + t0 * row_bytes;
+    const uint32_t voff = ((bl >> 6) * T * 64u + (bl & 63u)) * 4u + t0 * row_bytes;   // SMPC_GM_INDEX(bl, t0, T) in 32 bits
     const uint32_t vprev = sg ? voff - row_bytes : voff;   // (segment 0: loaded, not used)
     auto ld = [&](uint32_t tensor, uint32_t i) -> float {
       return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, voff, tensor * noise_bytes + i * row_bytes, 0));
