@@ -1065,7 +1065,7 @@ def test_reference_smoke_fixture(Smpc, Oracle, model):
 
 @pytest.mark.parametrize("B,T,off", [(70000, 64, 0), (65536, 40, 131072), (61441, 56, 7)])
 def test_fused_time_major_fill_is_the_same_stream(Smpc, monkeypatch, B, T, off):
-    """A lane-per-rollout context draws its device-RNG noise straight into the time-major layout
+    """A lane-per-rollout context draws its device-RNG noise straight into the group-major layout
     (smpc_fill_noise_tm) and makes the [B,T] copy only on demand: bit for bit the tensors of the
     two-step path (fill [B,T], transpose), for a whole batch and for a shard of a larger one;
     and the lane pass's tick on them equals the tick on the same tensors handed over through
