@@ -305,6 +305,10 @@ struct smpc_ctx {
   float hint_drift = 0.f;    // last tick's (true - predicted): how fast the endpoints drift relative to the robot
   bool anchor_valid = false;
   double anchor_x = 0, anchor_y = 0;
+  // endpoint of the NOMINAL rollout (the control sequence a tick starts from, no noise) of the last
+  // remembered tick and of the tick at hand: what carries the furthest point from tick to tick
+  double anchor_ex = 0, anchor_ey = 0, cur_ex = 0, cur_ey = 0;
+  bool anchor_e_valid = false, cur_e_valid = false;
   std::vector<float> anchor_px, anchor_py;
   // completion polling on the host-mapped result (SMPC_NO_POLL=1 disables)
   bool poll_enabled = true;
@@ -358,7 +362,7 @@ int check_tick(smpc_ctx* c, const smpc_tick_in* in);
 // the furthest point F (index + fraction) is now known for the tick inputs `in`: the next
 // prediction starts from here
 void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F);
-void predict_hint(smpc_ctx* c, const smpc_tick_in* in);
+void predict_hint(smpc_ctx* c, const smpc_tick_in* in, const float* u_in);
 int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in);
 
 int launch_furthest(smpc_ctx* c, float* d_furthest);

@@ -178,6 +178,10 @@ void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F)
   c->hint_valid = true;
   c->anchor_x = in->pose_x;
   c->anchor_y = in->pose_y;
+  c->anchor_ex = c->cur_ex;
+  c->anchor_ey = c->cur_ey;
+  c->anchor_e_valid = c->cur_e_valid;
+  c->cur_e_valid = false;
   c->anchor_px.assign(in->path_x, in->path_x + in->path_len);
   c->anchor_py.assign(in->path_y, in->path_y + in->path_len);
   c->anchor_valid = true;
@@ -192,8 +196,43 @@ void remember_furthest(smpc_ctx* c, const smpc_tick_in* in, float F)
 // number of points the plan lost at its start (the old point the new first point coincides
 // with).  F' = F + displacement - shift, index = round(F').  Exactness never depends on this:
 // the scoring pass reports the true value and a miss is re-scored.
-void predict_hint(smpc_ctx* c, const smpc_tick_in* in)
+// Where the rollout WITHOUT noise ends: pose + sum of the rotated state velocities (v[0] the measured
+// speed, v[t] = u[t - 1]; optimizer.cpp:258-267, 313-343), in double with the rotation advanced by
+// its Taylor terms — this feeds the prediction only, 0.2 us per tick.
+static void nominal_endpoint(const smpc_ctx* c, const smpc_tick_in* in, const float* u, double& ex, double& ey)
 {
+  const uint32_t T = c->cfg.time_steps;
+  const double dt = c->cfg.model_dt;
+  double co = std::cos(static_cast<double>(in->pose_yaw)), si = std::sin(static_cast<double>(in->pose_yaw));
+  double x = 0.0, y = 0.0;
+  double vx = in->speed_vx, vy = c->holonomic ? in->speed_vy : 0.0, wz = in->speed_wz;
+  for (uint32_t t = 0; t < T; ++t) {
+    x += (vx * co - vy * si) * dt;      // cos_[t] = cos(yaw[t - 1])
+    y += (vx * si + vy * co) * dt;
+    const double a = wz * dt, a2 = a * a;
+    const double ca = 1.0 - 0.5 * a2 + a2 * a2 * (1.0 / 24.0), sa = a * (1.0 - a2 * (1.0 / 6.0));
+    const double cn = co * ca - si * sa;
+    si = si * ca + co * sa;
+    co = cn;
+    vx = u[t];
+    vy = c->holonomic ? u[T + t] : 0.0;
+    wz = u[2 * T + t];
+  }
+  ex = in->pose_x + x;
+  ey = in->pose_y + y;
+}
+
+void predict_hint(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
+{
+  // The rollouts are the nominal one plus the SAME noise tick after tick: their furthest point
+  // moves with the nominal endpoint — the robot's motion and the change of the control sequence
+  // (a sequence still accelerating reaches further every tick, and stops doing so where it meets
+  // the constraints: the kink a tick-to-tick drift estimate overshoots).
+  c->cur_e_valid = false;
+  if (u_in) {
+    nominal_endpoint(c, in, u_in, c->cur_ex, c->cur_ey);
+    c->cur_e_valid = true;
+  }
   if (!c->hint_valid || !c->anchor_valid) return;
   const uint32_t P0 = static_cast<uint32_t>(c->anchor_px.size()), P = in->path_len;
   c->hint = smpc_furthest_index(c->hint_F);
@@ -229,8 +268,13 @@ void predict_hint(smpc_ctx* c, const smpc_tick_in* in)
   const float sx = (S0 + 1 < P0 ? 1.f : -1.f) * (ox[Sn] - ox[S0]), sy = (S0 + 1 < P0 ? 1.f : -1.f) * (oy[Sn] - oy[S0]);
   const float seg2 = sx * sx + sy * sy;
   if (!(seg2 > 0.f)) return;
-  const float disp = static_cast<float>((in->pose_x - c->anchor_x) * sx + (in->pose_y - c->anchor_y) * sy) / seg2;
-  if (!(std::fabs(disp) < 4.f)) return;     // a jump, not a controller period's motion
+  // displacement along the plan at the furthest point, in segment lengths: of the nominal endpoint
+  // when both ticks have one, else of the pose alone
+  const bool by_endpoint = c->cur_e_valid && c->anchor_e_valid;
+  const double dx = by_endpoint ? c->cur_ex - c->anchor_ex : in->pose_x - c->anchor_x;
+  const double dy = by_endpoint ? c->cur_ey - c->anchor_ey : in->pose_y - c->anchor_y;
+  const float disp = static_cast<float>(dx * sx + dy * sy) / seg2;
+  if (!(std::fabs(disp) < (by_endpoint ? 8.f : 4.f))) return;     // a jump, not a controller period's motion
   const float Fp0 = c->hint_F + disp - static_cast<float>(k);   // carried by the geometry alone
   const float Fp = Fp0 + c->hint_drift;                          // ... and by last tick's drift
   c->hint_Fp = Fp0;
@@ -966,7 +1010,7 @@ int prepare_tick(smpc_ctx* c, const smpc_tick_in* in, const float* u_in)
   rc = plan_launch(c, in, gates, nsamp, mode_now);
   if (rc != SMPC_OK) return rc;
 
-  predict_hint(c, in);
+  predict_hint(c, in, u_in);
   c->gate_flags = gates;
   // with a footprint the two collision critics no longer see the same set of colliding rollouts,
   // and a pass reports one non-colliding count (CostCritic's, scored first): smpc_optimize counts
