@@ -108,10 +108,14 @@ def make_ctx(B, T, map_size, shard_offset=0, global_batch=0, seed=1234, flags=0,
 CLOCK_WARMUP_MS = 200.0     # --clock-warmup-ms: every timed context gets the same treatment
 
 
-def raise_clocks(g, ms, seed=1234):
-    """Bring the device's clocks up before the warm-up ticks: `ms` milliseconds of the device RNG's
-    redraw kernel (compute-bound, the product's own), then the seed again — the stored noise is
-    bit for bit what it was.  From idle the shader clock takes ~150 ms of load to climb from 2.0
+def raise_clocks(g, ms, seed=1234, scn=None):
+    """Bring the device's clocks up before the warm-up ticks: `ms` milliseconds of the workload's own
+    ticks (scn given), then smpc_reset and the seed again — the context is bit for bit where it was:
+    stored noise, no furthest-point prediction, the caller's warm-started control sequence — so the W
+    warm-up ticks and the K timed ones start from the same state as without it.  (Round 2 used the
+    device RNG's redraw kernel for this; it is write-bound, and a 5 + 20 run behind it still read
+    3-5 % slower than its own later ticks: SMPC_BENCH_CLOCK_WARMUP=redraw keeps it, and contexts
+    without a scene — the multi-query group — use it.)  From idle the shader clock takes ~150 ms of load to climb from 2.0
     to 2.34 GHz (rocm-smi samples: tools/clock_watch.py), so the first ~60 ticks of a fresh
     process run 10-20 % slower than the rest (tools/ramp.py, tools/warm_ticks.py: ticks 5-24 take
     481 us cold, 419 us behind this; steady state ~410).  The metric is steady-state throughput:
@@ -120,9 +124,16 @@ def raise_clocks(g, ms, seed=1234):
         return
     import torch
     t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < ms:
-        g.redraw_noise()
-        torch.cuda.synchronize()
+    if scn is not None and os.environ.get("SMPC_BENCH_CLOCK_WARMUP", "ticks") == "ticks":
+        u = scn.u0
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            un, _ = g.optimize(scn.tick, u)
+            u = shift(un)
+        g.reset()
+    else:
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            g.redraw_noise()
+            torch.cuda.synchronize()
     g.seed(seed)
     torch.cuda.synchronize()
 
@@ -252,7 +263,7 @@ def run_moving(step_fn, scn, dt, steps, warmup, sync, barrier):
 def time_config(B, T, map_size, steps, warmup, flags=0, redraw=False, critics=None):
     import torch
     g, scn, cfg = make_ctx(B, T, map_size, flags=flags, critics=critics)
-    raise_clocks(g, CLOCK_WARMUP_MS)
+    raise_clocks(g, CLOCK_WARMUP_MS, scn=scn)
     # regenerate_noises = true: the next epoch is requested behind every tick and drawn in the
     # background (smpc_redraw_noise_async: the reference's noise thread); the next tick waits for
     # it on the device, so in this back-to-back loop the whole draw is inside the timed region
@@ -588,7 +599,7 @@ def main():
     loop = compiled_for(headline_kind)
 
     # the timed region: exactly K ticks, no event records in the stream
-    raise_clocks(g, args.clock_warmup_ms)
+    raise_clocks(g, args.clock_warmup_ms, scn=None if sharded else scn)   # (N > 1: the redraw kernel; no single-GPU ticks on a shard)
     el, _, _, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
                                       torch.cuda.synchronize, barrier, compiled=loop)
     # the same K ticks issued from this interpreter (Smpc.optimize + numpy shift per tick)
@@ -710,10 +721,14 @@ def main():
             },
             "clock_warmup": {
                 "ms": args.clock_warmup_ms,
-                "what": "device-RNG redraw kernels in front of the W warm-up ticks, then the seed again (the stored "
-                        "noise is unchanged); --clock-warmup-ms 0 turns it off.  From idle the shader clock climbs "
-                        "from 2.0 to 2.34 GHz over ~150 ms of load (tools/clock_watch.py): without this, ticks 5-24 of a "
-                        "fresh process take 481 us, behind it 419 us, in steady state ~410 us (tools/warm_ticks.py)",
+                "what": ("ticks of this workload in front of the W warm-up ticks, then smpc_reset and the seed again: the "
+                         "context is back where it started (stored noise unchanged, no furthest-point prediction)"
+                         if os.environ.get("SMPC_BENCH_CLOCK_WARMUP", "ticks") == "ticks" and not sharded else
+                         "device-RNG redraw kernels in front of the W warm-up ticks, then the seed again (the stored "
+                         "noise is unchanged)")
+                        + "; --clock-warmup-ms 0 turns it off.  From idle the shader clock climbs from 2.0 to 2.34 GHz over "
+                          "~150 ms of load (tools/clock_watch.py): without this, ticks 5-24 of a fresh process take 481 us, "
+                          "in steady state ~400 us (tools/warm_ticks.py)",
             },
             "moving_pose": {
                 "ms_per_step": 1e3 * el_mv / args.steps,
