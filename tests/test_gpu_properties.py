@@ -92,6 +92,31 @@ def test_full_size_shards_sum_to_the_whole(B, T, M):
     assert rel_err(u_s, u_w) < 5e-6
 
 
+@pytest.mark.parametrize("B,T", [(4096, 56), (70000, 64)])
+def test_reset_and_seed_put_a_context_back_where_it_started(B, T):
+    """bench.py warms the clocks with the workload's own ticks and then calls smpc_reset and smpc_seed:
+    after that a context has to behave bit for bit like a fresh one — the same noise, no
+    furthest-point prediction (first tick: the furthest-only pass in front), the same ticks after."""
+    fresh, scn = _ctx(B, T, 200, seed=11)
+    used, _ = _ctx(B, T, 200, seed=11)
+    u = scn.u0
+    for _ in range(12):
+        un, _ = used.optimize(scn.tick, u)
+        u = np.concatenate([un[:, 1:], un[:, -1:]], axis=1)
+    used.reset()
+    used.seed(11)
+    ua = ub = scn.u0
+    for k in range(4):
+        ua, oa = fresh.optimize(scn.tick, ua)
+        ub, ob = used.optimize(scn.tick, ub)
+        assert np.array_equal(ua, ub), k
+        assert np.array_equal(fresh.get_costs(), used.get_costs()), k
+        for f in ("passes", "pass_kind", "furthest_reached_path_point", "non_colliding", "min_cost", "sum_w"):
+            assert getattr(oa, f) == getattr(ob, f), (k, f)
+        ua = np.concatenate([ua[:, 1:], ua[:, -1:]], axis=1)
+        ub = np.concatenate([ub[:, 1:], ub[:, -1:]], axis=1)
+
+
 def test_multi_query_replicas_are_independent():
     """configs[4] in miniature: several planning instances (own costmap seed, pose, plan, noise)
     packed on one GPU; each must equal its own oracle, whatever the others do."""
