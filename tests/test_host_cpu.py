@@ -71,3 +71,22 @@ def test_host_needs_a_gpu(host):
     with pytest.raises(RuntimeError, match="no HIP device"):
         host.Optimizer(default_config(batch_size=64, time_steps=30), default_critics(),
                        controller_frequency=20.0)
+
+
+def test_compiled_tick_loop_rejects_bad_arguments_without_a_gpu(host):
+    """sortham_run_ticks (host/tick_loop.cpp): null context / inputs / zero horizon are SMPC_ERR_INVALID
+    before anything touches a device; *done stays 0."""
+    import ctypes as C
+    from mpcholonavigation_amd import _abi as A
+    lib = host.load_library()
+    done = C.c_uint32(7)
+    outs = (A.SmpcTickOut * 2)()
+    u = np.zeros((3, 8), np.float32)
+    tick = A.SmpcTickIn()
+    assert lib.sortham_run_ticks(None, C.byref(tick), ptr(u), 8, 2, 1, outs, C.byref(done)) == A.SMPC_ERR_INVALID
+    assert done.value == 0
+    fake = C.c_void_p(1)      # never dereferenced: the checks come first
+    assert lib.sortham_run_ticks(fake, None, ptr(u), 8, 2, 1, outs, None) == A.SMPC_ERR_INVALID
+    assert lib.sortham_run_ticks(fake, C.byref(tick), None, 8, 2, 1, outs, None) == A.SMPC_ERR_INVALID
+    assert lib.sortham_run_ticks(fake, C.byref(tick), ptr(u), 0, 2, 1, outs, None) == A.SMPC_ERR_INVALID
+    assert lib.sortham_run_ticks(fake, C.byref(tick), ptr(u), 8, 2, 1, None, None) == A.SMPC_ERR_INVALID
