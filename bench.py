@@ -599,7 +599,28 @@ def main():
     loop = compiled_for(headline_kind)
 
     # the timed region: exactly K ticks, no event records in the stream
-    raise_clocks(g, args.clock_warmup_ms, scn=None if sharded else scn)   # (N > 1: the redraw kernel; no single-GPU ticks on a shard)
+    if sharded and args.clock_warmup_ms > 0 and os.environ.get("SMPC_BENCH_CLOCK_WARMUP", "ticks") == "ticks":
+        # N > 1: the same warm-up with the SHARDED tick (a collective: every rank follows rank 0's clock, in
+        # blocks of 50 ticks), then reset + seed on every rank and the Python driver's state cleared
+        flag = torch.zeros(1, device="cuda")
+        u_w = scn.u0
+        t_w = time.perf_counter()
+        while True:
+            for _ in range(50):
+                un_w, _ = step_fn(scn.tick, u_w)
+                u_w = shift(un_w)
+            flag[0] = 1.0 if (time.perf_counter() - t_w) * 1e3 >= args.clock_warmup_ms else 0.0
+            dist.broadcast(flag, src=0)
+            if float(flag.item()) > 0.0:
+                break
+        g.reset()
+        g.seed(1234)
+        if hasattr(so, "hint"):
+            so.hint = None
+        torch.cuda.synchronize()
+        barrier()
+    else:
+        raise_clocks(g, args.clock_warmup_ms, scn=None if sharded else scn)
     el, _, _, passes, out = run_ticks(step_fn, scn, args.steps, args.warmup,
                                       torch.cuda.synchronize, barrier, compiled=loop)
     # the same K ticks issued from this interpreter (Smpc.optimize + numpy shift per tick)
@@ -723,7 +744,7 @@ def main():
                 "ms": args.clock_warmup_ms,
                 "what": ("ticks of this workload in front of the W warm-up ticks, then smpc_reset and the seed again: the "
                          "context is back where it started (stored noise unchanged, no furthest-point prediction)"
-                         if os.environ.get("SMPC_BENCH_CLOCK_WARMUP", "ticks") == "ticks" and not sharded else
+                         if os.environ.get("SMPC_BENCH_CLOCK_WARMUP", "ticks") == "ticks" else
                          "device-RNG redraw kernels in front of the W warm-up ticks, then the seed again (the stored "
                          "noise is unchanged)")
                         + "; --clock-warmup-ms 0 turns it off.  From idle the shader clock climbs from 2.0 to 2.34 GHz over "
