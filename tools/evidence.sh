@@ -50,8 +50,10 @@ TAILAB_SIZES=12288x56,16384x56,20000x60,32768x56,32768x48 python3 $ROOT/tools/ta
 # 3d. the N > 1 code path of bench.py with two processes on this one GPU (RCCL refuses that: the torch/gloo driver
 # carries the headline, the mailbox exchange beside it), then with the stand-in for the nccl* symbols
 ( export SMPC_BENCH_SHARE_GPU=1 SMPC_BENCH_BACKEND=gloo
-  python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $ROOT/bench.py --gpus 2 --steps 20 --warmup 3 --total-rollouts 131072 > "$OUT/bench_2ranks_one_gpu_rehearsal.json" 2> "$OUT/bench_2ranks.stderr"
-  SMPC_RCCL_LIB=$ROOT/tests/fake_rccl/libfake_rccl.so python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 $ROOT/bench.py --gpus 2 --steps 20 --warmup 3 --total-rollouts 131072 > "$OUT/bench_2ranks_one_gpu_standin_rehearsal.json" 2> "$OUT/bench_2ranks_standin.stderr" )
+  python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $ROOT/bench.py --gpus 2 --steps 20 --warmup 5 --total-rollouts 131072 > "$OUT/bench_2ranks_one_gpu_rehearsal.json" 2> "$OUT/bench_2ranks.stderr"
+  SMPC_RCCL_LIB=$ROOT/tests/fake_rccl/libfake_rccl.so python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 $ROOT/bench.py --gpus 2 --steps 20 --warmup 5 --total-rollouts 131072 > "$OUT/bench_2ranks_one_gpu_standin_rehearsal.json" 2> "$OUT/bench_2ranks_standin.stderr" )
+# 3e. ... and with the real RCCL in a one-rank communicator
+SMPC_BENCH_FORCE_DIST=1 python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --total-rollouts 262144 --no-other-configs --no-cpu-baseline > "$OUT/bench_1rank_rccl_rehearsal.json" 2> /dev/null
 # 4. where a tick's fixed cost goes
 : > "$OUT/tick_timeline.txt"
 for BT in "2000 56" "65536 64" "262144 64"; do
